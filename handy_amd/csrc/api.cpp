@@ -1,0 +1,395 @@
+// extern "C" surface of libwhisper_mi355.so: the whisper.h ABI subset whisper-rs binds, plus wmi.h.
+// Every entry point returns an error code / NULL instead of throwing or aborting: Handy's release
+// profile is panic = "abort" (reference: src-tauri/Cargo.toml:113), so nothing may unwind across here.
+#include <stdarg.h>
+#include <string.h>
+
+#include <chrono>
+#include <fstream>
+#include <mutex>
+#include <new>
+
+#include "engine.h"
+
+using namespace wmi;
+
+// ------------------------------------------------------------------------------------------ logging
+static ggml_log_callback g_log_cb = nullptr;
+static void *g_log_ud = nullptr;
+static std::mutex g_log_mu;
+
+namespace wmi {
+void log_msg(int level, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    if (g_log_cb) g_log_cb(level, buf, g_log_ud);
+    else fputs(buf, stderr);
+}
+}  // namespace wmi
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+#define WMI_TRY try {
+#define WMI_CATCH(ret)                                                                   \
+    } catch (const std::exception &e) { wmi::log_msg(2, "%s: %s\n", __func__, e.what()); return ret; } \
+    catch (...) { wmi::log_msg(2, "%s: unknown failure\n", __func__); return ret; }
+
+extern "C" {
+
+void whisper_log_set(ggml_log_callback cb, void *ud) { std::lock_guard<std::mutex> lk(g_log_mu); g_log_cb = cb; g_log_ud = ud; }
+
+const char *whisper_print_system_info(void) {
+    static char info[256];
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    hipDeviceProp_t pr{};
+    if (ndev > 0 && hipGetDeviceProperties(&pr, 0) == hipSuccess) snprintf(info, sizeof info, "HIP = 1 | devices = %d | device0 = %s (%s) | MFMA_F16 = 1 | ", ndev, pr.name, pr.gcnArchName);
+    else snprintf(info, sizeof info, "HIP = 0 | ");
+    return info;
+}
+const char *wmi_version(void) { return "whisper-mi355 0.1.0 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------ lifetime
+struct whisper_context_params whisper_context_default_params(void) {
+    whisper_context_params p{};
+    p.use_gpu = true; p.flash_attn = false; p.gpu_device = 0; p.dtw_token_timestamps = false; p.dtw_aheads_preset = WHISPER_AHEADS_NONE;
+    p.dtw_n_top = -1; p.dtw_aheads.n_heads = 0; p.dtw_aheads.heads = nullptr; p.dtw_mem_size = 1024 * 1024 * 128;
+    return p;
+}
+struct whisper_context_params *whisper_context_default_params_by_ref(void) {
+    whisper_context_params *p = (whisper_context_params *)malloc(sizeof *p);
+    if (p) *p = whisper_context_default_params();
+    return p;
+}
+void whisper_free_context_params(struct whisper_context_params *p) { free(p); }
+void whisper_free_params(struct whisper_full_params *p) { free(p); }
+
+struct whisper_context *whisper_init_from_buffer_with_params_no_state(void *buffer, size_t size, struct whisper_context_params params) {
+    WMI_TRY
+    if (!buffer || size < 64) { wmi::log_msg(2, "whisper_init: empty model buffer\n"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { wmi::log_msg(2, "whisper_init: no HIP device available (this engine has no CPU path)\n"); return nullptr; }
+    if (params.gpu_device < 0 || params.gpu_device >= ndev) { wmi::log_msg(2, "whisper_init: gpu_device %d out of range (%d devices)\n", params.gpu_device, ndev); return nullptr; }
+    const double t0 = now_ms();
+    Model *m = load_model((const uint8_t *)buffer, size, params.gpu_device);
+    if (!m) return nullptr;
+    whisper_context *ctx = new whisper_context();
+    ctx->model = m; ctx->params = params; ctx->t_load_ms = now_ms() - t0;
+    return ctx;
+    WMI_CATCH(nullptr)
+}
+struct whisper_context *whisper_init_from_file_with_params_no_state(const char *path, struct whisper_context_params params) {
+    WMI_TRY
+    if (!path) return nullptr;
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { wmi::log_msg(2, "whisper_init: failed to open '%s'\n", path); return nullptr; }
+    const std::streamsize sz = f.tellg();
+    if (sz <= 0) { wmi::log_msg(2, "whisper_init: '%s' is empty\n", path); return nullptr; }
+    std::vector<char> buf((size_t)sz);
+    f.seekg(0);
+    if (!f.read(buf.data(), sz)) { wmi::log_msg(2, "whisper_init: failed to read '%s'\n", path); return nullptr; }
+    return whisper_init_from_buffer_with_params_no_state(buf.data(), buf.size(), params);
+    WMI_CATCH(nullptr)
+}
+struct whisper_state *wmi_init_state_batch(struct whisper_context *ctx, int max_utts, int max_decoders, int enc_chunk) {
+    WMI_TRY
+    if (!ctx || !ctx->model) return nullptr;
+    Engine *e = new Engine(ctx->model, max_utts, max_decoders, enc_chunk);
+    if (!e->ok()) { wmi::log_msg(2, "whisper_init_state: failed to allocate device workspaces\n"); delete e; return nullptr; }
+    whisper_state *s = new whisper_state();
+    s->engine = e; s->ctx = ctx;
+    return s;
+    WMI_CATCH(nullptr)
+}
+struct whisper_state *whisper_init_state(struct whisper_context *ctx) { return wmi_init_state_batch(ctx, 1, 8, 1); }
+
+struct whisper_context *whisper_init_from_file_with_params(const char *path, struct whisper_context_params params) {
+    whisper_context *ctx = whisper_init_from_file_with_params_no_state(path, params);
+    if (!ctx) return nullptr;
+    ctx->default_state = whisper_init_state(ctx);
+    if (!ctx->default_state) { whisper_free(ctx); return nullptr; }
+    return ctx;
+}
+struct whisper_context *whisper_init_from_buffer_with_params(void *buffer, size_t size, struct whisper_context_params params) {
+    whisper_context *ctx = whisper_init_from_buffer_with_params_no_state(buffer, size, params);
+    if (!ctx) return nullptr;
+    ctx->default_state = whisper_init_state(ctx);
+    if (!ctx->default_state) { whisper_free(ctx); return nullptr; }
+    return ctx;
+}
+void whisper_free_state(struct whisper_state *s) {
+    if (!s) return;
+    try { delete s->engine; } catch (...) {}
+    delete s;
+}
+void whisper_free(struct whisper_context *ctx) {
+    if (!ctx) return;
+    whisper_free_state(ctx->default_state);
+    try { delete ctx->model; } catch (...) {}
+    delete ctx;
+}
+
+// ------------------------------------------------------------------------------------------ low-level stages
+#define ENG(s) ((s) && (s)->engine ? (s)->engine : nullptr)
+
+int whisper_pcm_to_mel_with_state(struct whisper_context *, struct whisper_state *s, const float *samples, int n, int) {
+    WMI_TRY
+    Engine *e = ENG(s); if (!e) return -1;
+    return e->pcm_to_mel(samples, n);
+    WMI_CATCH(-1)
+}
+int whisper_pcm_to_mel(struct whisper_context *ctx, const float *samples, int n, int nt) { return ctx ? whisper_pcm_to_mel_with_state(ctx, ctx->default_state, samples, n, nt) : -1; }
+int whisper_set_mel_with_state(struct whisper_context *, struct whisper_state *s, const float *data, int n_len, int n_mel) {
+    WMI_TRY
+    Engine *e = ENG(s); if (!e) return -1;
+    return e->set_mel(data, n_len, n_mel);
+    WMI_CATCH(-1)
+}
+int whisper_set_mel(struct whisper_context *ctx, const float *data, int n_len, int n_mel) { return ctx ? whisper_set_mel_with_state(ctx, ctx->default_state, data, n_len, n_mel) : -1; }
+int whisper_encode_with_state(struct whisper_context *, struct whisper_state *s, int offset, int) {
+    WMI_TRY
+    Engine *e = ENG(s); if (!e) return -1;
+    return e->encode(offset, e->exp_n_audio_ctx) == 0 ? 0 : -1;
+    WMI_CATCH(-1)
+}
+int whisper_encode(struct whisper_context *ctx, int offset, int nt) { return ctx ? whisper_encode_with_state(ctx, ctx->default_state, offset, nt) : -1; }
+int whisper_decode_with_state(struct whisper_context *, struct whisper_state *s, const whisper_token *tokens, int n_tokens, int n_past, int) {
+    WMI_TRY
+    Engine *e = ENG(s); if (!e) return -1;
+    return e->decode(tokens, n_tokens, n_past, false, nullptr) == 0 ? 0 : 1;
+    WMI_CATCH(1)
+}
+int whisper_decode(struct whisper_context *ctx, const whisper_token *tokens, int n_tokens, int n_past, int nt) { return ctx ? whisper_decode_with_state(ctx, ctx->default_state, tokens, n_tokens, n_past, nt) : -1; }
+float *whisper_get_logits_from_state(struct whisper_state *s) { Engine *e = ENG(s); return e ? e->logits_host() : nullptr; }
+float *whisper_get_logits(struct whisper_context *ctx) { return ctx ? whisper_get_logits_from_state(ctx->default_state) : nullptr; }
+int wmi_decode_logits_all(struct whisper_context *, struct whisper_state *s, const whisper_token *tokens, int n_tokens, int n_past, float *out) {
+    WMI_TRY
+    Engine *e = ENG(s); if (!e || !out) return -1;
+    return e->decode(tokens, n_tokens, n_past, true, out);
+    WMI_CATCH(-1)
+}
+
+int whisper_tokenize(struct whisper_context *ctx, const char *text, whisper_token *tokens, int n_max) {
+    WMI_TRY
+    if (!ctx || !text) return -1;
+    const std::vector<int> t = tokenize(ctx->model->vocab, text);
+    if ((int)t.size() > n_max) return -(int)t.size();
+    for (size_t i = 0; i < t.size(); i++) tokens[i] = t[i];
+    return (int)t.size();
+    WMI_CATCH(-1)
+}
+int whisper_token_count(struct whisper_context *ctx, const char *text) { return -whisper_tokenize(ctx, text, nullptr, 0); }
+
+int whisper_lang_max_id(void) { return kNumLangs - 1; }
+int whisper_lang_id(const char *lang) { const int id = lang_id_from_str(lang); if (id < 0) wmi::log_msg(2, "whisper_lang_id: unknown language '%s'\n", lang ? lang : "(null)"); return id; }
+const char *whisper_lang_str(int id) { return lang_str(id); }
+const char *whisper_lang_str_full(int id) { return lang_str_full(id); }
+int whisper_lang_auto_detect_with_state(struct whisper_context *, struct whisper_state *s, int offset_ms, int, float *probs) {
+    WMI_TRY
+    Engine *e = ENG(s); if (!e) return -1;
+    return e->lang_auto_detect(offset_ms, probs);
+    WMI_CATCH(-1)
+}
+int whisper_lang_auto_detect(struct whisper_context *ctx, int offset_ms, int nt, float *probs) { return ctx ? whisper_lang_auto_detect_with_state(ctx, ctx->default_state, offset_ms, nt, probs) : -1; }
+
+int whisper_n_len_from_state(struct whisper_state *s) { Engine *e = ENG(s); return e ? e->n_len() : 0; }
+int whisper_n_len(struct whisper_context *ctx) { return ctx ? whisper_n_len_from_state(ctx->default_state) : 0; }
+#define HP(ctx, f) ((ctx) && (ctx)->model ? (ctx)->model->hp.f : 0)
+int whisper_n_vocab(struct whisper_context *c) { return HP(c, n_vocab); }
+int whisper_n_text_ctx(struct whisper_context *c) { return HP(c, n_text_ctx); }
+int whisper_n_audio_ctx(struct whisper_context *c) { return HP(c, n_audio_ctx); }
+int whisper_is_multilingual(struct whisper_context *c) { return c && c->model && c->model->vocab.multilingual() ? 1 : 0; }
+int whisper_model_n_vocab(struct whisper_context *c) { return HP(c, n_vocab); }
+int whisper_model_n_audio_ctx(struct whisper_context *c) { return HP(c, n_audio_ctx); }
+int whisper_model_n_audio_state(struct whisper_context *c) { return HP(c, n_audio_state); }
+int whisper_model_n_audio_head(struct whisper_context *c) { return HP(c, n_audio_head); }
+int whisper_model_n_audio_layer(struct whisper_context *c) { return HP(c, n_audio_layer); }
+int whisper_model_n_text_ctx(struct whisper_context *c) { return HP(c, n_text_ctx); }
+int whisper_model_n_text_state(struct whisper_context *c) { return HP(c, n_text_state); }
+int whisper_model_n_text_head(struct whisper_context *c) { return HP(c, n_text_head); }
+int whisper_model_n_text_layer(struct whisper_context *c) { return HP(c, n_text_layer); }
+int whisper_model_n_mels(struct whisper_context *c) { return HP(c, n_mels); }
+int whisper_model_ftype(struct whisper_context *c) { return HP(c, ftype); }
+int whisper_model_type(struct whisper_context *c) {
+    switch (HP(c, n_audio_layer)) { case 4: return 1; case 6: return 2; case 12: return 3; case 24: return 4; case 32: return 5; }
+    return 0;
+}
+const char *whisper_model_type_readable(struct whisper_context *c) { return c && c->model ? c->model->type_name.c_str() : ""; }
+
+const char *whisper_token_to_str(struct whisper_context *c, whisper_token t) {
+    if (!c || !c->model || t < 0 || t >= c->model->hp.n_vocab) return "";
+    return c->model->vocab.id_to_token[t].c_str();
+}
+#define VOC(c, f) ((c) && (c)->model ? (c)->model->vocab.f : -1)
+whisper_token whisper_token_eot(struct whisper_context *c) { return VOC(c, eot); }
+whisper_token whisper_token_sot(struct whisper_context *c) { return VOC(c, sot); }
+whisper_token whisper_token_solm(struct whisper_context *c) { return VOC(c, solm); }
+whisper_token whisper_token_prev(struct whisper_context *c) { return VOC(c, prev); }
+whisper_token whisper_token_nosp(struct whisper_context *c) { return VOC(c, nosp); }
+whisper_token whisper_token_not(struct whisper_context *c) { return VOC(c, tok_not); }
+whisper_token whisper_token_beg(struct whisper_context *c) { return VOC(c, beg); }
+whisper_token whisper_token_translate(struct whisper_context *c) { return VOC(c, translate); }
+whisper_token whisper_token_transcribe(struct whisper_context *c) { return VOC(c, transcribe); }
+whisper_token whisper_token_lang(struct whisper_context *c, int lang_id) { return c && c->model ? c->model->token_lang(lang_id) : -1; }
+
+void whisper_print_timings(struct whisper_context *ctx) {
+    if (!ctx) return;
+    wmi::log_msg(1, "\nwhisper_print_timings:     load time = %8.2f ms\n", ctx->t_load_ms);
+    if (Engine *e = ENG(ctx->default_state)) {
+        wmi::log_msg(1, "whisper_print_timings:      mel time = %8.2f ms\n", e->t_mel_ms);
+        wmi::log_msg(1, "whisper_print_timings:   encode time = %8.2f ms / %5d windows\n", e->t_encode_ms, e->n_encode);
+        wmi::log_msg(1, "whisper_print_timings:   decode time = %8.2f ms / %5d rows\n", e->t_decode_ms, e->n_decode);
+    }
+}
+void whisper_reset_timings(struct whisper_context *ctx) {
+    if (!ctx) return;
+    if (Engine *e = ENG(ctx->default_state)) { e->t_mel_ms = e->t_encode_ms = e->t_decode_ms = 0; e->n_encode = e->n_decode = 0; }
+}
+
+// ------------------------------------------------------------------------------------------ full pipeline
+struct whisper_full_params whisper_full_default_params(enum whisper_sampling_strategy strategy) {
+    whisper_full_params p{};
+    p.strategy = strategy;
+    p.n_threads = 4; p.n_max_text_ctx = 16384; p.offset_ms = 0; p.duration_ms = 0;
+    p.translate = false; p.no_context = true; p.no_timestamps = false; p.single_segment = false; p.print_special = false;
+    p.print_progress = true; p.print_realtime = false; p.print_timestamps = true;
+    p.token_timestamps = false; p.thold_pt = 0.01f; p.thold_ptsum = 0.01f; p.max_len = 0; p.split_on_word = false; p.max_tokens = 0;
+    p.debug_mode = false; p.audio_ctx = 0; p.tdrz_enable = false; p.suppress_regex = nullptr;
+    p.initial_prompt = nullptr; p.prompt_tokens = nullptr; p.prompt_n_tokens = 0;
+    p.language = "en"; p.detect_language = false;
+    p.suppress_blank = true; p.suppress_nst = false;
+    p.temperature = 0.0f; p.max_initial_ts = 1.0f; p.length_penalty = -1.0f;
+    p.temperature_inc = 0.2f; p.entropy_thold = 2.4f; p.logprob_thold = -1.0f; p.no_speech_thold = 0.6f;
+    p.greedy.best_of = -1; p.beam_search.beam_size = -1; p.beam_search.patience = -1.0f;
+    if (strategy == WHISPER_SAMPLING_GREEDY) p.greedy.best_of = 5;
+    else p.beam_search.beam_size = 5;
+    return p;
+}
+struct whisper_full_params *whisper_full_default_params_by_ref(enum whisper_sampling_strategy strategy) {
+    whisper_full_params *p = (whisper_full_params *)malloc(sizeof *p);
+    if (p) *p = whisper_full_default_params(strategy);
+    return p;
+}
+
+int wmi_full_batch(struct whisper_context *ctx, struct whisper_state *s, struct whisper_full_params params, const float *const *samples, const int *n_samples, int n_utts, int on_device) {
+    WMI_TRY
+    Engine *e = ENG(s);
+    if (!ctx || !e) return -1;
+    return e->full_batch(ctx, s, params, samples, n_samples, n_utts, on_device != 0);
+    WMI_CATCH(-1)
+}
+int whisper_full_with_state(struct whisper_context *ctx, struct whisper_state *s, struct whisper_full_params params, const float *samples, int n_samples) {
+    const float *ptrs[1] = {samples};
+    const int ns[1] = {n_samples};
+    static const float zero = 0.0f;
+    if (n_samples == 0) ptrs[0] = &zero;
+    return wmi_full_batch(ctx, s, params, ptrs, ns, 1, 0);
+}
+int whisper_full(struct whisper_context *ctx, struct whisper_full_params params, const float *samples, int n_samples) {
+    return ctx ? whisper_full_with_state(ctx, ctx->default_state, params, samples, n_samples) : -1;
+}
+int whisper_full_parallel(struct whisper_context *ctx, struct whisper_full_params params, const float *samples, int n_samples, int) {
+    return whisper_full(ctx, params, samples, n_samples);
+}
+
+// ------------------------------------------------------------------------------------------ readout
+static const Segment *seg_at(struct whisper_state *s, int utt, int i) {
+    Engine *e = ENG(s);
+    if (!e || utt < 0 || utt >= (int)e->results.size()) return nullptr;
+    const auto &v = e->results[utt].segs;
+    return i >= 0 && i < (int)v.size() ? &v[i] : nullptr;
+}
+int wmi_batch_n_utts(struct whisper_state *s) { Engine *e = ENG(s); return e ? (int)e->results.size() : 0; }
+int wmi_batch_n_segments(struct whisper_state *s, int utt) { Engine *e = ENG(s); return e && utt >= 0 && utt < (int)e->results.size() ? (int)e->results[utt].segs.size() : 0; }
+int64_t wmi_batch_segment_t0(struct whisper_state *s, int utt, int i) { const Segment *g = seg_at(s, utt, i); return g ? g->t0 : 0; }
+int64_t wmi_batch_segment_t1(struct whisper_state *s, int utt, int i) { const Segment *g = seg_at(s, utt, i); return g ? g->t1 : 0; }
+const char *wmi_batch_segment_text(struct whisper_state *s, int utt, int i) { const Segment *g = seg_at(s, utt, i); return g ? g->text.c_str() : ""; }
+int wmi_batch_n_tokens(struct whisper_state *s, int utt, int i) { const Segment *g = seg_at(s, utt, i); return g ? (int)g->tokens.size() : 0; }
+whisper_token_data wmi_batch_token_data(struct whisper_state *s, int utt, int i, int j) {
+    const Segment *g = seg_at(s, utt, i);
+    if (!g || j < 0 || j >= (int)g->tokens.size()) { whisper_token_data z{}; return z; }
+    return g->tokens[j];
+}
+int wmi_batch_lang_id(struct whisper_state *s, int utt) { Engine *e = ENG(s); return e && utt >= 0 && utt < (int)e->results.size() ? e->results[utt].lang_id : -1; }
+int wmi_batch_n_fallbacks(struct whisper_state *s, int utt) { Engine *e = ENG(s); return e && utt >= 0 && utt < (int)e->results.size() ? e->results[utt].n_fallbacks : 0; }
+
+int whisper_full_n_segments_from_state(struct whisper_state *s) { return wmi_batch_n_segments(s, 0); }
+int whisper_full_n_segments(struct whisper_context *c) { return c ? whisper_full_n_segments_from_state(c->default_state) : 0; }
+int whisper_full_lang_id_from_state(struct whisper_state *s) { return wmi_batch_lang_id(s, 0); }
+int whisper_full_lang_id(struct whisper_context *c) { return c ? whisper_full_lang_id_from_state(c->default_state) : -1; }
+int64_t whisper_full_get_segment_t0_from_state(struct whisper_state *s, int i) { return wmi_batch_segment_t0(s, 0, i); }
+int64_t whisper_full_get_segment_t0(struct whisper_context *c, int i) { return c ? whisper_full_get_segment_t0_from_state(c->default_state, i) : 0; }
+int64_t whisper_full_get_segment_t1_from_state(struct whisper_state *s, int i) { return wmi_batch_segment_t1(s, 0, i); }
+int64_t whisper_full_get_segment_t1(struct whisper_context *c, int i) { return c ? whisper_full_get_segment_t1_from_state(c->default_state, i) : 0; }
+bool whisper_full_get_segment_speaker_turn_next_from_state(struct whisper_state *s, int i) { const Segment *g = seg_at(s, 0, i); return g ? g->speaker_turn_next : false; }
+bool whisper_full_get_segment_speaker_turn_next(struct whisper_context *c, int i) { return c ? whisper_full_get_segment_speaker_turn_next_from_state(c->default_state, i) : false; }
+const char *whisper_full_get_segment_text_from_state(struct whisper_state *s, int i) { return wmi_batch_segment_text(s, 0, i); }
+const char *whisper_full_get_segment_text(struct whisper_context *c, int i) { return c ? whisper_full_get_segment_text_from_state(c->default_state, i) : ""; }
+int whisper_full_n_tokens_from_state(struct whisper_state *s, int i) { return wmi_batch_n_tokens(s, 0, i); }
+int whisper_full_n_tokens(struct whisper_context *c, int i) { return c ? whisper_full_n_tokens_from_state(c->default_state, i) : 0; }
+whisper_token_data whisper_full_get_token_data_from_state(struct whisper_state *s, int i, int j) { return wmi_batch_token_data(s, 0, i, j); }
+whisper_token_data whisper_full_get_token_data(struct whisper_context *c, int i, int j) { return whisper_full_get_token_data_from_state(c ? c->default_state : nullptr, i, j); }
+whisper_token whisper_full_get_token_id_from_state(struct whisper_state *s, int i, int j) { return wmi_batch_token_data(s, 0, i, j).id; }
+whisper_token whisper_full_get_token_id(struct whisper_context *c, int i, int j) { return whisper_full_get_token_id_from_state(c ? c->default_state : nullptr, i, j); }
+float whisper_full_get_token_p_from_state(struct whisper_state *s, int i, int j) { return wmi_batch_token_data(s, 0, i, j).p; }
+float whisper_full_get_token_p(struct whisper_context *c, int i, int j) { return whisper_full_get_token_p_from_state(c ? c->default_state : nullptr, i, j); }
+const char *whisper_full_get_token_text_from_state(struct whisper_context *c, struct whisper_state *s, int i, int j) { return whisper_token_to_str(c, wmi_batch_token_data(s, 0, i, j).id); }
+const char *whisper_full_get_token_text(struct whisper_context *c, int i, int j) { return c ? whisper_full_get_token_text_from_state(c, c->default_state, i, j) : ""; }
+
+// ------------------------------------------------------------------------------------------ wmi extras
+void wmi_set_force_tokens(struct whisper_state *s, int n) { if (Engine *e = ENG(s)) e->force_tokens = n; }
+void wmi_set_beam_candidates_sampled(struct whisper_state *s, int v) { if (Engine *e = ENG(s)) e->beam_sampled = v != 0; }
+int wmi_mel_batch_device(struct whisper_context *, struct whisper_state *s, const float *pcm_dev, const long long *offsets, const int *n, int B) {
+    WMI_TRY
+    Engine *e = ENG(s); if (!e || !pcm_dev || !offsets || !n || B <= 0) return -1;
+    return e->mel_batch_device(pcm_dev, offsets, n, B);
+    WMI_CATCH(-1)
+}
+int wmi_get_mel(struct whisper_state *s, int utt, float *out, int n_frames) {
+    WMI_TRY
+    Engine *e = ENG(s); return e && out ? e->get_mel(utt, out, n_frames) : -1;
+    WMI_CATCH(-1)
+}
+int wmi_get_encoder_output(struct whisper_state *s, float *out) {
+    WMI_TRY
+    Engine *e = ENG(s); return e && out ? e->get_encoder_output(out) : -1;
+    WMI_CATCH(-1)
+}
+int wmi_get_cross_kv(struct whisper_state *s, int layer, float *k, float *v) {
+    WMI_TRY
+    Engine *e = ENG(s); return e && k && v ? e->get_cross_kv(layer, k, v) : -1;
+    WMI_CATCH(-1)
+}
+void wmi_set_profiling(struct whisper_state *s, int on) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = on != 0; } }
+int wmi_get_kernel_stats(struct whisper_state *s, wmi_kernel_stat *out) {
+    Engine *e = ENG(s); if (!e || !out) return -1;
+    try { e->collect_stats(); } catch (...) { return -1; }
+    memcpy(out, e->stats, sizeof(wmi_kernel_stat) * WMI_K_COUNT);
+    return 0;
+}
+void wmi_reset_kernel_stats(struct whisper_state *s) { if (Engine *e = ENG(s)) e->reset_stats(); }
+
+int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C) {
+    WMI_TRY
+    if (M <= 0 || N % 64 || K % 64 || !A || !W || !C) return -1;
+    const int Mp = round_up(M, 128);
+    std::vector<f16> a((size_t)Mp * K, (f16)0.0f), w((size_t)N * K);
+    for (size_t i = 0; i < (size_t)M * K; i++) a[i] = (f16)A[i];
+    for (size_t i = 0; i < (size_t)N * K; i++) w[i] = (f16)W[i];
+    f16 *da = nullptr, *dw = nullptr; float *dc = nullptr;
+    int rc = -1;
+    if (hipMalloc(&da, a.size() * 2) == hipSuccess && hipMalloc(&dw, w.size() * 2) == hipSuccess && hipMalloc(&dc, (size_t)Mp * N * 4) == hipSuccess &&
+        hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+        gemm_f32(da, K, dw, K, M, N, K, dc, N, nullptr, nullptr) && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(C, dc, (size_t)M * N * 4, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = 0;
+    (void)hipFree(da); (void)hipFree(dw); (void)hipFree(dc);
+    return rc;
+    WMI_CATCH(-1)
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// Batched whisper_full engine: per-utterance state machines on the host drive batched encoder
+// chunks and decoder passes on one GPU stream.
+#pragma once
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/wmi.h"
+#include "model.h"
+
+namespace wmi {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes, bool zero = true);
+    void release();
+    template <class T> T *as() const { return (T *)p; }
+};
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes);
+    void release();
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct Segment {
+    int64_t t0 = 0, t1 = 0;
+    std::string text;
+    std::vector<whisper_token_data> tokens;
+    bool speaker_turn_next = false;
+};
+struct UttResult {
+    std::vector<Segment> segs;
+    int lang_id = 0, n_fallbacks = 0, rc = 0;
+};
+
+struct Sequence {
+    std::vector<whisper_token_data> tokens;
+    int result_len = 0;
+    double sum_logprobs_all = 0, sum_logprobs = 0, avg_logprobs = 0, entropy = 0, score = 0;
+};
+
+struct Decoder {
+    Sequence seq;
+    int seek_delta = 0;
+    bool failed = false, completed = false, has_ts = false;
+    std::vector<int> pages;      // self-attention KV pages of this sequence, in position order
+    int n_kv = 0;                // tokens whose K/V are in the cache
+    std::mt19937 rng;
+    SampleOut so{};              // selection computed from the latest logits of this sequence
+    TopkOut topk[8];
+    std::vector<float> probs;    // full probability row when the host has to draw from it
+};
+
+enum class Phase { LangEncode, LangDecode, Encode, Prompt, Step, Done };
+
+struct Utt {
+    int index = 0;               // position in the caller's batch
+    int slot = 0;                // cross-attention K/V slot == position inside the running group
+    int mel_idx = 0;
+    int n_len = 0, n_len_org = 0;
+    Phase phase = Phase::Done;
+    int seek = 0, seek_start = 0, seek_end = 0;
+    int it = 0, n_cur = 1, i = 0, n_prompt = 0;
+    float t_cur = 0;
+    std::vector<float> temps;
+    std::vector<int> prompt, prompt_past, prompt_init;
+    std::vector<Decoder> dec;
+    int best = 0;
+    int lang_id = 0;
+    bool no_timestamps = false;
+    bool encoded_at_seek = false; // the cross K/V in the slot already belong to window `seek`
+    int rc = 0;
+};
+
+struct PassRowRef { int utt, dec; };   // which (utterance, decoder) a logit row belongs to
+
+class Engine {
+public:
+    Engine(Model *m, int max_utts, int max_dec, int enc_chunk);
+    ~Engine();
+    bool ok() const { return ok_; }
+
+    // whisper_full semantics over a batch
+    int full_batch(whisper_context *ctx, whisper_state *st, const whisper_full_params &params, const float *const *pcm, const int *n, int B, bool on_device);
+
+    // low-level stages (utterance slot 0)
+    int pcm_to_mel(const float *pcm, int n);
+    int mel_batch_device(const float *pcm_dev, const long long *offs, const int *n, int B);
+    int set_mel(const float *data, int n_len, int n_mel);
+    int encode(int offset, int audio_ctx);
+    int decode(const int *tokens, int n_tokens, int n_past, bool logits_all, float *logits_all_out);
+    int lang_auto_detect(int offset_ms, float *probs);
+    int n_len() const { return utt_n_len_org_.empty() ? 0 : utt_n_len_org_[0]; }
+    float *logits_host() { return logits_host_.data(); }
+    int get_mel(int utt, float *out, int n_frames);
+    int get_encoder_output(float *out);
+    int get_cross_kv(int layer, float *k_out, float *v_out);
+
+    Model *model;
+    std::vector<UttResult> results;
+    int force_tokens = 0;
+    bool beam_sampled = false;
+    int exp_n_audio_ctx = 0;
+
+    // profiling
+    bool profiling = false;
+    wmi_kernel_stat stats[WMI_K_COUNT]{};
+    void collect_stats();
+    void reset_stats();
+    // timings (ms, host clock around synchronised phases)
+    double t_mel_ms = 0, t_encode_ms = 0, t_decode_ms = 0, t_load_ms = 0;
+    int n_encode = 0, n_decode = 0;
+
+private:
+    bool ok_ = false;
+    int max_utts_, max_dec_, enc_chunk_;
+    hipStream_t stream_ = nullptr;
+    int d_, H_, Le_, Ld_, T_full_, n_mel_, V_, Vp_;
+
+    // mel
+    DevBuf pcm_, mel_raw_, mel_max_, mel_utt_dev_, mel_norm_tmp_;
+    std::vector<MelUtt> mel_utt_;
+    std::vector<int> utt_n_len_, utt_n_len_org_;
+    bool mel_user_ = false;          // whisper_set_mel: mel_raw_ holds an already normalised mel
+
+    // encoder workspace
+    DevBuf melT_, h1_, x_, xn_, q_, k_, vt_, att_, hid_, enc16_, enc32_, win_dev_, slots_dev_;
+    int enc_T_ = 0;                  // audio context of the last encode (cross K/V length)
+    DevBuf ckv_;
+    int Tp_full_ = 0;
+
+    // decoder workspace
+    int rows_cap_ = 0, lrows_cap_ = 0;
+    DevBuf dx_, dxn_, dq_, datt_, dhid_, dxl_, logits_, probs_;
+    DevBuf kpool_, vpool_;
+    int n_pages_ = 0;
+    long layer_stride_ = 0;
+    std::vector<int> free_pages_, page_ref_;
+    DevBuf meta_dev_, out_dev_;
+    PinnedBuf meta_host_, out_host_, probs_host_;
+    std::vector<float> logits_host_;
+    Decoder ll_dec_;                 // sequence used by whisper_decode()
+
+    // event pool for profiling
+    struct EvPair { hipEvent_t a, b; int cls; double work; };
+    std::vector<EvPair> ev_pool_;
+    size_t ev_used_ = 0;
+    void prof_begin(int cls, double work);
+    void prof_end();
+    bool prof_open_ = false;
+
+    bool alloc_workspaces();
+    bool ensure_rows(int rows);
+    bool compute_mel(const float *pcm_dev_base, const std::vector<long> &offs, const std::vector<int> &n);
+    bool encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32);
+    struct PassOut { std::vector<SampleOut> so; std::vector<TopkOut> topk; };
+    bool decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow> &srows, const std::vector<const Decoder *> &seqs,
+                      const std::vector<int2> &page_copies, int T, bool want_raw_logits_host, float *logits_all_out);
+    // KV pages
+    int page_alloc();
+    void page_release(std::vector<int> &pages);
+    bool append_kv_slot(Decoder &d, int pos, std::vector<int2> &copies, int &kv_index);
+
+    // whisper_full pieces
+    struct Run;
+    friend struct Run;
+};
+
+}  // namespace wmi
+
+struct whisper_context {
+    wmi::Model *model = nullptr;
+    whisper_state *default_state = nullptr;
+    whisper_context_params params{};
+    double t_load_ms = 0;
+};
+struct whisper_state {
+    wmi::Engine *engine = nullptr;
+    whisper_context *ctx = nullptr;
+    std::string token_text_tmp;
+};

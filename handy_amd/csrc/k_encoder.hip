@@ -1,0 +1,207 @@
+// Encoder-side kernels for gfx950: row LayerNorm and the non-causal multi-head attention.
+#include "kernels.h"
+
+namespace wmi {
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row, the row held in registers (d <= 1280*... up to 5 float4 per lane), two-pass
+// statistics (mean, then centred variance) like the reference. Bound: HBM (4*d in, 2*d out per row).
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                                                         f16 *__restrict__ out16, float *__restrict__ out32, int M, int d, const int *__restrict__ gather) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const long src = gather ? gather[row] : row;
+    const f32x4 *xr = (const f32x4 *)(x + src * d);
+    const int nch = d >> 2;
+    f32x4 v[5];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int c = lane + 64 * i;
+        v[i] = f32x4{0, 0, 0, 0};
+        if (c < nch) { v[i] = xr[c]; sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)d;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int c = lane + 64 * i;
+        if (c < nch) { v[i] -= mean; sq += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]); }
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float scale = 1.0f / sqrtf(sq / (float)d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const f32x4 ww = *(const f32x4 *)(w + 4 * c), bb = *(const f32x4 *)(b + 4 * c);
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; k++) y[k] = v[i][k] * scale * ww[k] + bb[k];
+            if (out16) *(f16x4 *)(out16 + (long)row * d + 4 * c) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+            if (out32) *(f32x4 *)(out32 + (long)row * d + 4 * c) = y;
+        }
+    }
+}
+
+bool layer_norm(const float *x, const float *w, const float *b, f16 *out16, float *out32, int M, int d, const int *gather, hipStream_t st) {
+    if (M <= 0) return true;
+    if (d % 4 != 0 || d > 1280) { log_msg(2, "layer_norm: unsupported width %d\n", d); return false; }
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, w, b, out16, out32, M, d, gather);
+    return hipGetLastError() == hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------ attention
+// Non-causal softmax(Q K^T) V over T keys, heads of 64. Q is pre-scaled by 1/8 (exact in fp16).
+// Workgroup = 4 waves = 128 query rows of one (utterance, head); each wave owns 32 rows and walks
+// the keys in tiles of 64 staged through LDS (register-staged, double-buffered, XOR-swizzled).
+//   S^T = K Q^T      v_mfma_f32_32x32x16_f16, K rows as the A operand: a lane then holds scores of
+//                    ONE query (its column) for 16 keys per 32-key half, so the running max / sum
+//                    are per-lane scalars plus one exchange with the other lane half.
+//   O^T += V^T P^T   P^T is taken straight from the S^T accumulators (converted to fp16) as the B
+//                    operand; V arrives pre-transposed ([dh][key], written that way by the QKV GEMM
+//                    epilogue), read in the k-order the accumulator layout implies.
+// Bound: MFMA (4*T*T*64 flop per head). The output tile goes through LDS so rows are stored whole.
+constexpr float kLog2e = 1.4426950408889634f;
+
+__global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restrict__ Q, const f16 *__restrict__ K, const f16 *__restrict__ Vt,
+                                                            f16 *__restrict__ att, int H, int T, int Tp) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];    // per stage: K tile 8 KB + V^T tile 8 KB
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    if ((int)blockIdx.x * 128 >= T) return;       // query rows that are all padding
+    const long bh = (long)b * H + head;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const f16 *qp = Q + (bh * Tp + q0 + r) * 64 + 8 * h;
+    f16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) qf[ks] = *(const f16x8 *)(qp + 16 * ks);
+
+    const f16 *kg = K + bh * Tp * 64;
+    const f16 *vg = Vt + bh * 64 * Tp;
+    const int srow = tid >> 2, sc = (tid & 3) * 2;
+    f16x8 pk[2], pv[2];
+    auto load_tile = [&](int kt) {
+        const f16 *ks = kg + ((long)kt * 64 + srow) * 64 + sc * 8;
+        pk[0] = *(const f16x8 *)ks; pk[1] = *(const f16x8 *)(ks + 8);
+        const f16 *vs = vg + (long)srow * Tp + kt * 64 + sc * 8;
+        pv[0] = *(const f16x8 *)vs; pv[1] = *(const f16x8 *)(vs + 8);
+    };
+    auto store_tile = [&](int buf) {
+        char *kb = smem + buf * 16384, *vb = kb + 8192;
+        const int sw = (srow >> 1) & 7;
+        *(f16x8 *)(kb + srow * 128 + (((sc) ^ sw) << 4)) = pk[0];
+        *(f16x8 *)(kb + srow * 128 + (((sc + 1) ^ sw) << 4)) = pk[1];
+        const int sv = (srow >> 1) & 15;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const f16x4 lo = {pv[i][0], pv[i][1], pv[i][2], pv[i][3]}, hi = {pv[i][4], pv[i][5], pv[i][6], pv[i][7]};
+            const int c8 = (sc + i) * 2;
+            *(f16x4 *)(vb + srow * 128 + (((c8) ^ sv) << 3)) = lo;
+            *(f16x4 *)(vb + srow * 128 + (((c8 + 1) ^ sv) << 3)) = hi;
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { o0[i] = 0.0f; o1[i] = 0.0f; }
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int n_tiles = (T + 63) / 64;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < n_tiles; kt++) {
+        const char *kb = smem + (kt & 1) * 16384, *vb = kb + 8192;
+        if (kt + 1 < n_tiles) load_tile(kt + 1);
+        f32x16 s[2];
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[kh][i] = 0.0f;
+            const int row = kh * 32 + r, sw = (row >> 1) & 7;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const f16x8 kf = *(const f16x8 *)(kb + row * 128 + (((2 * ks + h) ^ sw) << 4));
+                s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kh], 0, 0, 0);
+            }
+        }
+        if (kt == n_tiles - 1 && (T & 63)) {          // mask keys past the end
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int key = kt * 64 + kh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= T) s[kh][i] = -INFINITY;
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[kh][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+        const float mb = m_new * kLog2e;
+        float lsum = 0.0f;
+        f16x8 pf[2][2];
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float p = __builtin_amdgcn_exp2f(s[kh][i] * kLog2e - mb);
+                lsum += p;
+                pf[kh][i >> 3][i & 7] = (f16)p;
+            }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int sidx = 0; sidx < 2; sidx++) {
+                const int c8 = kh * 8 + 4 * sidx + h;
+#pragma unroll
+                for (int blk = 0; blk < 2; blk++) {
+                    const int row = blk * 32 + r, sv = (row >> 1) & 15;
+                    const f16x4 lo = *(const f16x4 *)(vb + row * 128 + ((c8 ^ sv) << 3));
+                    const f16x4 hi = *(const f16x4 *)(vb + row * 128 + (((c8 + 2) ^ sv) << 3));
+                    const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (blk == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][sidx], o0, 0, 0, 0);
+                    else o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][sidx], o1, 0, 0, 0);
+                }
+            }
+        if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+    // normalise, stage the [128 q][64 dh] tile in LDS, store whole rows
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    char *ob = smem;
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x16 &o = blk ? o1 : o0;
+            const f16x4 v4 = {(f16)(o[4 * g] * inv), (f16)(o[4 * g + 1] * inv), (f16)(o[4 * g + 2] * inv), (f16)(o[4 * g + 3] * inv)};
+            *(f16x4 *)(ob + (wave * 32 + r) * 128 + (blk * 32 + 8 * g + 4 * h) * 2) = v4;
+        }
+    __syncthreads();
+    const int d = H * 64;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int idx = p * 256 + tid, row = idx >> 3, ch = idx & 7, q = blockIdx.x * 128 + row;
+        if (q < T) *(f16x8 *)(att + ((long)b * T + q) * d + head * 64 + ch * 8) = *(const f16x8 *)(ob + row * 128 + ch * 16);
+    }
+}
+
+bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st) {
+    if (B <= 0) return true;
+    if (Tp % 128 != 0 || T > Tp) { log_msg(2, "enc_attention: bad padding T=%d Tp=%d\n", T, Tp); return false; }
+    hipLaunchKernelGGL(enc_attention_kernel, dim3(Tp / 128, H, B), dim3(256), 0, st, Q, K, Vt, att, H, T, Tp);
+    return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace wmi

@@ -1,0 +1,262 @@
+// Log-mel frontend for gfx950 (restates whisper.cpp's log_mel_spectrogram semantics):
+//   padded = [reflect(samples[1..200]) | samples | zeros], frame i = padded[160 i .. 160 i + 400) * Hann(400, periodic)
+//   400-point real DFT -> 201 power bins -> filterbank (double accumulation) -> log10(max(., 1e-10))
+//   then, per utterance, clamp to (max - 8) and map to (x + 4) / 4.
+//
+// One workgroup (256 threads) produces 16 consecutive frames:
+//   1. the 2800 input samples the 16 frames share are read once from HBM into LDS (coalesced);
+//   2. each 400-sample real frame is packed into a 200-point complex sequence and transformed in
+//      LDS by a fp32 mixed-radix FFT (200 = 8 x 5 x 5: one radix-8 pass + twiddles, two radix-5
+//      passes), followed by the real-FFT unpacking pass that yields the 201 power bins;
+//   3. the filterbank is applied over each mel bin's nonzero support only (bit-identical to the
+//      dense sum, whose other terms are exact zeros), accumulated in double like the reference;
+//   4. raw log10 values go to HBM mel-major and the per-utterance maximum is folded with one
+//      atomicMax per workgroup. The clamp/scale pass is fused into whatever consumes the mel
+//      (encoder window extraction) because it needs the global maximum.
+// Bound: HBM. Algorithmic bytes per 30 s utterance: 480000*4 in + n_mel*3000*4 out.
+#include "kernels.h"
+
+namespace wmi {
+
+constexpr int F = kMelFramesPerBlock;          // frames per workgroup
+constexpr int NS = (F - 1) * kHop + kNFft;     // samples shared by the frames
+constexpr int PSTRIDE = 209;                   // power row stride (odd: conflict-free column reads)
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }   // a * (+i)
+
+__device__ __forceinline__ void dft4(float2 a, float2 b, float2 c, float2 d, float2 *o) {
+    float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+    o[0] = cadd(t0, t2); o[2] = csub(t0, t2);
+    o[1] = cadd(t1, mul_mi(t3)); o[3] = cadd(t1, mul_pi(t3));
+}
+__device__ __forceinline__ void dft8(float2 *v) {
+    float2 e[4], o[4];
+    dft4(v[0], v[2], v[4], v[6], e);
+    dft4(v[1], v[3], v[5], v[7], o);
+    const float r = 0.70710678118654752440f;
+    o[1] = make_float2(r * (o[1].x + o[1].y), r * (o[1].y - o[1].x));      // * (1 - i)/sqrt2
+    o[2] = mul_mi(o[2]);                                                      // * (-i)
+    o[3] = make_float2(r * (o[3].y - o[3].x), -r * (o[3].x + o[3].y));     // * (-1 - i)/sqrt2
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+}
+__device__ __forceinline__ void dft5(float2 *v) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    float2 x0 = make_float2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+    float2 m1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+    float2 m2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+    float2 n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    float2 n2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    v[0] = x0;
+    v[1] = cadd(m1, mul_mi(n1)); v[4] = cadd(m1, mul_pi(n1));
+    v[2] = cadd(m2, mul_mi(n2)); v[3] = cadd(m2, mul_pi(n2));
+}
+
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+__global__ __launch_bounds__(256) void mel_raw_kernel(const float *__restrict__ pcm, const MelUtt *__restrict__ utts, MelTables tb,
+                                                      float *__restrict__ mel_out, unsigned *__restrict__ mel_max) {
+    __shared__ float2 z[F * 200];
+    __shared__ float sp[F * PSTRIDE];          // samples first (NS <= F*PSTRIDE), then the power spectra
+    __shared__ float2 tw[400];
+    __shared__ float hann[400];
+    __shared__ float wmax[4];
+    static_assert(NS <= F * PSTRIDE, "sample buffer too small");
+    const MelUtt u = utts[blockIdx.y];
+    const int f0 = blockIdx.x * F;
+    if (f0 >= u.n_frames) return;
+    const int tid = threadIdx.x;
+    float *out = mel_out + u.mel_off;
+    if (f0 >= u.n_calc) {                      // frames that see no audio: power 0 -> log10(1e-10)
+        for (int i = tid; i < F * tb.n_mel; i += 256) out[(long)(i / F) * u.n_frames + f0 + (i % F)] = -10.0f;
+        if (tid == 0) atomicMax(mel_max + blockIdx.y, ordered_bits(-10.0f));
+        return;
+    }
+    for (int i = tid; i < 400; i += 256) { tw[i] = tb.tw400[i]; hann[i] = tb.hann[i]; }
+    const float *x = pcm + u.pcm_off;
+    for (int i = tid; i < NS; i += 256) {
+        const long p = (long)f0 * kHop + i;
+        float v = 0.0f;
+        if (p < 200) { const long s = 200 - p; v = s < u.n ? x[s] : 0.0f; }
+        else { const long s = p - 200; v = s < u.n ? x[s] : 0.0f; }
+        sp[i] = v;
+    }
+    __syncthreads();
+    // windowed frame -> packed complex sequence z[m] = w[2m] x[2m] + i w[2m+1] x[2m+1]
+    for (int i = tid; i < F * 200; i += 256) {
+        const int f = i / 200, m = i - f * 200;
+        const float *s = sp + f * kHop + 2 * m;
+        z[i] = make_float2(hann[2 * m] * s[0], hann[2 * m + 1] * s[1]);
+    }
+    __syncthreads();
+    // pass 1: 25 radix-8 butterflies per frame over n = 25*n1 + n2, twiddle W200^(n2*k1), store at [k1][n2]
+    for (int i = tid; i < F * 25; i += 256) {
+        const int f = i / 25, n2 = i - f * 25;
+        float2 *zz = z + f * 200 + n2;
+        float2 v[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = zz[25 * a];
+        dft8(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; k1++) { const float2 w = tw[(2 * n2 * k1) % 400]; v[k1] = cmul(v[k1], make_float2(w.x, -w.y)); }
+#pragma unroll
+        for (int k1 = 0; k1 < 8; k1++) zz[25 * k1] = v[k1];
+    }
+    __syncthreads();
+    // pass 2a: per (k1, b) radix-5 over a of y[5a+b], twiddle W25^(b*c), store at [c][b]
+    for (int i = tid; i < F * 40; i += 256) {
+        const int f = i / 40, r = i - f * 40, k1 = r / 5, b = r - k1 * 5;
+        float2 *zz = z + f * 200 + k1 * 25 + b;
+        float2 v[5];
+#pragma unroll
+        for (int a = 0; a < 5; a++) v[a] = zz[5 * a];
+        dft5(v);
+#pragma unroll
+        for (int c = 1; c < 5; c++) { const float2 w = tw[(16 * b * c) % 400]; v[c] = cmul(v[c], make_float2(w.x, -w.y)); }
+#pragma unroll
+        for (int c = 0; c < 5; c++) zz[5 * c] = v[c];
+    }
+    __syncthreads();
+    // pass 2b: per (k1, c) radix-5 over b; result k = k1 + 8*(c + 5e). All reads before any write.
+    {
+        float2 v[3][5]; int base[3];
+#pragma unroll
+        for (int rnd = 0; rnd < 3; rnd++) {
+            const int i = tid + rnd * 256;
+            base[rnd] = -1;
+            if (i < F * 40) {
+                const int f = i / 40, r = i - f * 40, k1 = r / 5, c = r - k1 * 5;
+                const float2 *zz = z + f * 200 + k1 * 25 + c * 5;
+#pragma unroll
+                for (int b = 0; b < 5; b++) v[rnd][b] = zz[b];
+                dft5(v[rnd]);
+                base[rnd] = f * 200 + k1 + 8 * c;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rnd = 0; rnd < 3; rnd++)
+            if (base[rnd] >= 0) {
+#pragma unroll
+                for (int e = 0; e < 5; e++) z[base[rnd] + 40 * e] = v[rnd][e];
+            }
+    }
+    __syncthreads();
+    // real-FFT unpacking: X[k] = E[k] + W400^k O[k], E = (Z[k] + conj Z[200-k])/2, O = (Z[k] - conj Z[200-k])/(2i)
+    for (int i = tid; i < F * kNBins; i += 256) {
+        const int f = i / kNBins, k = i - f * kNBins;
+        const float2 a = z[f * 200 + (k == 200 ? 0 : k)];
+        float2 b = z[f * 200 + ((200 - k) % 200)];
+        b.y = -b.y;
+        const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+        const float2 dlt = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+        const float2 o = mul_mi(dlt);
+        const float2 w = tw[k % 400];
+        const float2 xo = cmul(o, make_float2(w.x, -w.y));
+        const float re = e.x + xo.x, im = e.y + xo.y;
+        sp[f * PSTRIDE + k] = re * re + im * im;
+    }
+    __syncthreads();
+    float lmax = -1e30f;
+    {
+        const int f = tid & (F - 1), jg = tid / F;
+        const float *pw = sp + f * PSTRIDE;
+        for (int j = jg; j < tb.n_mel; j += 256 / F) {
+            const int lo = tb.flo[j], hi = tb.fhi[j];
+            const float *fl = tb.filters + j * kNBins;
+            double sum = 0.0;
+            for (int k = lo; k < hi; k++) sum += (double)(pw[k] * fl[k]);
+            const float v = (float)log10(sum > 1e-10 ? sum : 1e-10);
+            out[(long)j * u.n_frames + f0 + f] = v;
+            lmax = fmaxf(lmax, v);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((tid & 63) == 0) wmax[tid >> 6] = lmax;
+    __syncthreads();
+    if (tid == 0) atomicMax(mel_max + blockIdx.y, ordered_bits(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
+bool mel_raw(const float *pcm, const MelUtt *utts, int n_utt, int max_blocks_per_utt, const MelTables &tb, float *mel_raw_out, unsigned *mel_max, hipStream_t st) {
+    if (n_utt <= 0 || max_blocks_per_utt <= 0) return true;
+    WMI_HIP_OK(hipMemsetAsync(mel_max, 0, sizeof(unsigned) * n_utt, st));
+    hipLaunchKernelGGL(mel_raw_kernel, dim3(max_blocks_per_utt, n_utt), dim3(256), 0, st, pcm, utts, tb, mel_raw_out, mel_max);
+    return hipGetLastError() == hipSuccess;
+}
+
+__device__ __forceinline__ float mel_norm_value(float raw, float mmax) {
+    // mirrors: mmax (double) -= 8; if (x < mmax) x = mmax; x = (x + 4) / 4
+    const double lim = (double)mmax - 8.0;
+    float v = raw;
+    if ((double)v < lim) v = (float)lim;
+    return (float)(((double)v + 4.0) / 4.0);
+}
+
+__global__ void mel_normalize_kernel(const float *raw, int n_mel, int n_frames, const unsigned *mel_max, float *out, int n_out) {
+    const float mmax = fmaxf(from_ordered_bits(*mel_max), -10.0f);
+    const long total = (long)n_mel * n_out;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i / n_out), t = (int)(i - (long)j * n_out);
+        const float r = t < n_frames ? raw[(long)j * n_frames + t] : -10.0f;
+        out[i] = mel_norm_value(r, mmax);
+    }
+}
+bool mel_normalize(const float *raw, int n_mel, int n_frames, const unsigned *mel_max, float *out, int n_out, hipStream_t st) {
+    const long total = (long)n_mel * n_out;
+    if (total <= 0) return true;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(mel_normalize_kernel, dim3(blocks), dim3(256), 0, st, raw, n_mel, n_frames, mel_max, out, n_out);
+    return hipGetLastError() == hipSuccess;
+}
+
+// window extraction + normalisation + transpose to [frame][mel] fp16 (the conv1 operand layout)
+template <bool NORMALIZED>
+__global__ __launch_bounds__(256) void mel_window_kernel(const float *__restrict__ src, const unsigned *__restrict__ mel_max, const WinDesc *__restrict__ wins,
+                                                         int n_mel, int T2, f16 *__restrict__ melT) {
+    __shared__ float tile[128 * 65];
+    const WinDesc w = wins[blockIdx.y];
+    const int t0 = blockIdx.x * 64;
+    const float mmax = NORMALIZED ? 0.0f : fmaxf(from_ordered_bits(mel_max[w.max_idx]), -10.0f);
+    const float *raw = src + w.mel_off;
+    for (int i = threadIdx.x; i < n_mel * 64; i += 256) {
+        const int j = i >> 6, tt = i & 63, t = t0 + tt, fr = w.seek + t;
+        float v = 0.0f;
+        if (t < T2 && fr < w.n_len) {
+            if (NORMALIZED) v = raw[(long)j * w.n_frames + fr];
+            else v = mel_norm_value(fr < w.n_frames ? raw[(long)j * w.n_frames + fr] : -10.0f, mmax);
+        }
+        tile[j * 65 + tt] = v;
+    }
+    __syncthreads();
+    f16 *dst = melT + ((long)blockIdx.y * (T2 + 2) + 1 + t0) * n_mel;
+    for (int i = threadIdx.x; i < n_mel * 64; i += 256) {
+        const int tt = i / n_mel, j = i - tt * n_mel;
+        if (t0 + tt < T2) dst[(long)tt * n_mel + j] = (f16)tile[j * 65 + tt];
+    }
+}
+bool mel_window(const float *raw, const unsigned *mel_max, const WinDesc *wins, int n_win, int n_mel, int T2, f16 *melT, hipStream_t st) {
+    if (n_win <= 0) return true;
+    if (n_mel > 128) return false;
+    hipLaunchKernelGGL(mel_window_kernel<false>, dim3((T2 + 63) / 64, n_win), dim3(256), 0, st, raw, mel_max, wins, n_mel, T2, melT);
+    return hipGetLastError() == hipSuccess;
+}
+bool mel_window_normalized(const float *mel, const WinDesc *wins, int n_win, int n_mel, int T2, f16 *melT, hipStream_t st) {
+    if (n_win <= 0) return true;
+    if (n_mel > 128) return false;
+    hipLaunchKernelGGL(mel_window_kernel<true>, dim3((T2 + 63) / 64, n_win), dim3(256), 0, st, mel, nullptr, wins, n_mel, T2, melT);
+    return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace wmi

@@ -1,0 +1,62 @@
+// Host-callable launchers of the HIP kernels (one translation unit per k_*.hip file).
+#pragma once
+#include "wmi_common.h"
+
+namespace wmi {
+
+// ---- k_gemm.hip : C[m][n] = sum_k A[m][k] W[n][k] with fused epilogues ----------------------
+bool gemm_f16(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st);
+bool gemm_f32(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, float *out, long ldc, const float *bias, hipStream_t st);
+bool gemm_residual(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, float *x, long ldc, const float *bias, hipStream_t st);
+bool gemm_conv1(const f16 *melT, int n_mel, const f16 *W, int Kpad, int M, int d, f16 *h1, const float *bias, int T2, hipStream_t st);
+bool gemm_conv2(const f16 *h1, const f16 *W, int M, int d, float *x, const float *bias, const float *pe, int T, hipStream_t st);
+bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *K, f16 *Vt, const float *bias, hipStream_t st);
+bool gemm_cross_kv(const f16 *enc, const f16 *W, int M, int d, int H, int T, int Tp, int n_layer, f16 *out, const float *bias, const int *slots, hipStream_t st);
+bool gemm_dec_qkv(const f16 *xn, const f16 *W, int M, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st);
+
+// ---- k_mel.hip : log-mel frontend -----------------------------------------------------------
+struct MelTables {           // device-resident constants of one model
+    const float *filters;    // [n_mel][201] dense table from the model file
+    const int   *flo, *fhi;  // per mel bin: nonzero support [lo, hi)
+    const float *hann;       // [400]
+    const float2 *tw400;     // [400] (cos, sin)(2*pi*m/400)
+    int n_mel;
+};
+struct MelUtt {              // one per utterance
+    long pcm_off;            // offset (samples) into the PCM buffer
+    int  n;                  // samples
+    int  n_frames;           // frames stored (multiple of kMelFramesPerBlock), raw layout [n_mel][n_frames]
+    int  n_calc;             // frames that see any audio
+    long mel_off;            // offset (floats) of this utterance's raw log-mel
+};
+constexpr int kMelFramesPerBlock = 16;
+// raw log10 mel (before the max-8 clamp) for every utterance + per-utterance max (as ordered uint)
+bool mel_raw(const float *pcm, const MelUtt *utts, int n_utt, int max_blocks_per_utt, const MelTables &tb, float *mel_raw, unsigned *mel_max, hipStream_t st);
+// normalised copy: out[j][i] for i < n_out frames (clamp to max-8, (x+4)/4); frames past n_frames read as -10
+bool mel_normalize(const float *raw, int n_mel, int n_frames, const unsigned *mel_max, float *out, int n_out, hipStream_t st);
+// encoder input windows: for chunk entry e, frames [seek[e], seek[e]+2T) of utterance utt[e] -> fp16 [e*(2T+2)+1+t][n_mel]
+struct WinDesc { long mel_off; int n_frames; int n_len; int seek; int max_idx; };
+bool mel_window(const float *raw, const unsigned *mel_max, const WinDesc *wins, int n_win, int n_mel, int T2, f16 *melT, hipStream_t st);
+// same, from an already normalised mel (whisper_set_mel): n_frames == n_len, no clamp applied
+bool mel_window_normalized(const float *mel, const WinDesc *wins, int n_win, int n_mel, int T2, f16 *melT, hipStream_t st);
+
+// ---- k_encoder.hip --------------------------------------------------------------------------
+// y = LayerNorm(x) * w + b (eps 1e-5); writes fp16 (out16) and/or fp32 (out32); rows gathered through `gather` if given
+bool layer_norm(const float *x, const float *w, const float *b, f16 *out16, float *out32, int M, int d, const int *gather, hipStream_t st);
+// non-causal attention over T keys (padded to Tp), heads of 64: Q,K [B][H][Tp][64], Vt [B][H][64][Tp] -> att [B*T][H*64]
+bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st);
+
+// ---- k_decoder.hip --------------------------------------------------------------------------
+bool dec_embed(const f16 *te, const float *pe, const DecRow *rows, int M, int d, float *x, hipStream_t st);
+// causal self-attention over the paged cache: kc/vc [page][H][16][64], block_table [seq][kMaxPagesPerSeq]
+bool dec_self_attention(const f16 *q, const f16 *kc, const f16 *vc, const int *block_table, const DecRow *rows, int M, int d, int H, f16 *att, hipStream_t st);
+// cross-attention over cached encoder K/V: ckv [slot][layer][2][H][Tp][64]
+bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, int M, int d, int H, int T, int Tp, int n_layer, int layer, f16 *att, hipStream_t st);
+// logits rules + log-softmax + argmax / top-k / probabilities for every logit row
+// (the masked logits are written back in place; nst_bitmap has one bit per token id)
+bool sample_rows(float *logits, long ld, int R, const SampleRow *srow, const VocabIds &vi, const unsigned *nst_bitmap,
+                 SampleOut *out, TopkOut *topk, int topk_stride, float *probs, hipStream_t st);
+// copy KV page contents in every layer (beam fork of a partially filled page): pairs of (src_page, dst_page)
+bool copy_pages(f16 *kpool, f16 *vpool, long layer_stride, int n_layer, const int2 *pairs, int n_pairs, int H, hipStream_t st);
+
+}  // namespace wmi

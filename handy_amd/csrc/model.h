@@ -1,0 +1,69 @@
+// Whisper model: legacy ggml file -> device-resident fp16/fp32 tensors in the layouts the kernels read.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+
+namespace wmi {
+
+struct HParams {
+    int n_vocab = 0, n_audio_ctx = 0, n_audio_state = 0, n_audio_head = 0, n_audio_layer = 0;
+    int n_text_ctx = 0, n_text_state = 0, n_text_head = 0, n_text_layer = 0, n_mels = 0, ftype = 0;
+};
+
+struct Vocab {
+    int n_vocab = 0;
+    std::vector<std::string> id_to_token;
+    std::unordered_map<std::string, int> token_to_id;
+    int eot = 50256, sot = 50257, translate = 50357, transcribe = 50358, solm = 50359, prev = 50360, nosp = 50361, tok_not = 50362, beg = 50363;
+    int space = -1;
+    bool multilingual() const { return n_vocab >= 51865; }
+    int num_languages() const { return n_vocab - 51765 - (multilingual() ? 1 : 0); }
+};
+
+struct EncLayer {
+    float *ln1_w, *ln1_b, *bqkv, *bo, *ln2_w, *ln2_b, *b1, *b2;
+    f16 *wqkv, *wo, *fc1, *fc2;
+};
+struct DecLayer {
+    float *ln1_w, *ln1_b, *bqkv, *bo, *lnx_w, *lnx_b, *bxq, *bxo, *ln2_w, *ln2_b, *b1, *b2;
+    f16 *wqkv, *wo, *xq, *xo, *fc1, *fc2;
+};
+
+struct Model {
+    HParams hp;
+    Vocab vocab;
+    int device = 0;
+    int conv1_kpad = 0;          // 3*n_mels rounded up to the GEMM K-step
+    int n_vocab_pad = 0;         // token-embedding rows rounded up to the GEMM N tile
+    MelTables mel{};
+    f16 *conv1_w = nullptr, *conv2_w = nullptr, *d_te = nullptr, *xkv_w = nullptr;
+    float *conv1_b = nullptr, *conv2_b = nullptr, *e_pe = nullptr, *ln_post_w = nullptr, *ln_post_b = nullptr;
+    float *d_pe = nullptr, *d_ln_w = nullptr, *d_ln_b = nullptr, *xkv_b = nullptr;
+    unsigned *nst_bitmap = nullptr;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    std::vector<void *> allocs;  // every device allocation, for release
+    size_t bytes = 0;
+    std::string type_name;
+
+    ~Model();
+    VocabIds vocab_ids() const;
+    int token_lang(int lang_id) const { return vocab.sot + 1 + lang_id; }
+};
+
+// Parses `data` (a whole ggml file image) and uploads it to `device`. Returns nullptr (after logging) on any
+// malformed, truncated or unsupported input.
+Model *load_model(const uint8_t *data, size_t size, int device);
+
+int lang_id_from_str(const char *s);
+const char *lang_str(int id);
+const char *lang_str_full(int id);
+constexpr int kNumLangs = 100;
+
+// greedy longest-match tokenizer over the model vocabulary (initial_prompt support)
+std::vector<int> tokenize(const Vocab &v, const std::string &text);
+
+}  // namespace wmi

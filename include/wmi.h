@@ -1,0 +1,74 @@
+/*
+ * wmi.h -- extensions of libwhisper_mi355.so next to the whisper.h ABI.
+ *
+ * Handy serialises every transcription behind one mutex, one utterance per call
+ * (reference: src-tauri/src/managers/transcription.rs:39, :383); its only concurrent caller,
+ * the Discord voice loop, queues N `transcribe` calls on that mutex
+ * (src-tauri/src/discord_conversation.rs:470-476). The batch entry points below are what a
+ * batch-aware caller (or an offline bulk driver) binds instead: the same whisper_full semantics
+ * applied to B independent utterances at once on one GPU. They have no counterpart in the
+ * reference; whisper_full_with_state() is wmi_full_batch() with B = 1.
+ */
+#ifndef WMI_H
+#define WMI_H
+
+#include "whisper.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A state sized for up to max_utts utterances in flight, each with up to max_decoders sequences
+ * (beam size / best_of, <= 8), encoder work issued in chunks of enc_chunk utterances (0 = default). */
+WHISPER_API struct whisper_state *wmi_init_state_batch(struct whisper_context *ctx, int max_utts, int max_decoders, int enc_chunk);
+
+/* whisper_full semantics for n_utts utterances. samples[i] points to n_samples[i] floats
+ * (16 kHz mono, [-1,1]) in HOST memory, or in DEVICE memory when samples_on_device != 0.
+ * Returns 0 or the first failing utterance's whisper_full error code. */
+WHISPER_API int wmi_full_batch(struct whisper_context *ctx, struct whisper_state *state, struct whisper_full_params params,
+                               const float *const *samples, const int *n_samples, int n_utts, int samples_on_device);
+
+/* Readout per utterance (whisper_full_*_from_state reads utterance 0). */
+WHISPER_API int wmi_batch_n_utts(struct whisper_state *state);
+WHISPER_API int wmi_batch_n_segments(struct whisper_state *state, int utt);
+WHISPER_API int64_t wmi_batch_segment_t0(struct whisper_state *state, int utt, int seg);
+WHISPER_API int64_t wmi_batch_segment_t1(struct whisper_state *state, int utt, int seg);
+WHISPER_API const char *wmi_batch_segment_text(struct whisper_state *state, int utt, int seg);
+WHISPER_API int wmi_batch_n_tokens(struct whisper_state *state, int utt, int seg);
+WHISPER_API whisper_token_data wmi_batch_token_data(struct whisper_state *state, int utt, int seg, int tok);
+WHISPER_API int wmi_batch_lang_id(struct whisper_state *state, int utt);
+WHISPER_API int wmi_batch_n_fallbacks(struct whisper_state *state, int utt);
+
+/* Benchmark control (no upstream counterpart): when n > 0 every decoded sequence is exactly n
+ * tokens long -- the end-of-text token is masked before position n and forced at it. Synthetic
+ * audio and random weights have no natural transcript length; this fixes the decode workload. */
+WHISPER_API void wmi_set_force_tokens(struct whisper_state *state, int n);
+/* Beam-search candidate rule: 0 = deterministic k most probable tokens per beam (default),
+ * 1 = k draws from the token distribution with a per-decoder mt19937 (what upstream does). */
+WHISPER_API void wmi_set_beam_candidates_sampled(struct whisper_state *state, int sampled);
+
+/* Log-mel only, for n_utts utterances already in DEVICE memory (pcm_dev + offsets[i], n_samples[i] floats):
+ * runs the frontend kernels and leaves the raw log-mel on the device. Used by the mel roofline probe. */
+WHISPER_API int wmi_mel_batch_device(struct whisper_context *ctx, struct whisper_state *state, const float *pcm_dev,
+                                     const long long *offsets, const int *n_samples, int n_utts);
+
+/* Inspection hooks used by the parity tests (all copy to host memory). */
+WHISPER_API int wmi_get_mel(struct whisper_state *state, int utt, float *out, int n_frames);          /* normalised [n_mel][n_frames] */
+WHISPER_API int wmi_get_encoder_output(struct whisper_state *state, float *out);                       /* last whisper_encode: [n_ctx][n_state] */
+WHISPER_API int wmi_get_cross_kv(struct whisper_state *state, int layer, float *k_out, float *v_out);  /* utterance slot 0: [n_ctx][n_state] each */
+WHISPER_API int wmi_decode_logits_all(struct whisper_context *ctx, struct whisper_state *state, const whisper_token *tokens, int n_tokens, int n_past, float *logits_out);
+WHISPER_API int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C);          /* C = f16(A) f16(W)^T on the device */
+
+/* Per-kernel-class device time, measured with HIP events on the engine's stream. */
+enum wmi_kernel_class { WMI_K_MEL = 0, WMI_K_ENC_GEMM, WMI_K_ENC_ATTN, WMI_K_ENC_OTHER, WMI_K_DEC_GEMM, WMI_K_DEC_CROSS_ATTN, WMI_K_DEC_OTHER, WMI_K_COUNT };
+typedef struct wmi_kernel_stat { double ms; double work; long long launches; } wmi_kernel_stat;  /* work: flop (GEMM/attention) or bytes */
+WHISPER_API void wmi_set_profiling(struct whisper_state *state, int enabled);
+WHISPER_API int wmi_get_kernel_stats(struct whisper_state *state, wmi_kernel_stat *out /* [WMI_K_COUNT] */);
+WHISPER_API void wmi_reset_kernel_stats(struct whisper_state *state);
+
+WHISPER_API const char *wmi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMI_H */

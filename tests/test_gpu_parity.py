@@ -1,0 +1,89 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle on the same
+seeded inputs (and against the committed Hugging Face fixtures)."""
+import numpy as np
+import pytest
+
+from handy_amd.synth import synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wr():
+    from handy_amd import whisper_rs
+    whisper_rs.load_library()
+    return whisper_rs
+
+
+def _f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 192, 256), (64, 64, 64), (1, 128, 128), (300, 256, 1280), (5, 51968 // 4, 128)])
+def test_gemm_matches_numpy(wr, M, N, K):
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K), dtype=np.float32)
+    W = rng.standard_normal((N, K), dtype=np.float32) + np.arange(N, dtype=np.float32)[:, None] * 0.01   # asymmetric
+    C = np.empty((M, N), np.float32)
+    L = wr.load_library()
+    assert L.wmi_debug_gemm(M, N, K, wr._fp(A), wr._fp(W), wr._fp(C)) == 0
+    ref = _f16(A).astype(np.float64) @ _f16(W).astype(np.float64).T
+    err = np.abs(C - ref).max()
+    assert err <= 2e-3 * max(1.0, np.abs(ref).max()), err
+
+
+@pytest.mark.parametrize("arch,n_mels", [("micro.en", 80), ("micro-v3", 128)])
+def test_mel_parity(wr, oracle, golden, model_path, arch, n_mels):
+    path = model_path(arch)
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    ctx = wr.WhisperContext(path); st = ctx.create_state()
+    for seed, secs in ((0, 1.0), (1, 5.0), (2, 29.9), (3, 30.0), (4, 0.03), (5, 12.3456)):
+        n = int(round(secs * 16000))
+        pcm = synth_pcm(seed, n)
+        ref = ost.pcm_to_mel(pcm)
+        st.pcm_to_mel(pcm)
+        assert st.n_len() == ost.n_len_org
+        got = st.get_mel(ref.shape[1])
+        err = np.abs(got - ref).max()
+        assert err <= 1e-3, (seed, secs, err)          # tolerance stated by the parity contract: log-mel max abs error <= 1e-3
+        key = f"mel{n_mels}_s{seed}"
+        if key in golden:
+            g = golden[key]
+            assert np.abs(got[:, :g.shape[1] * 8:8][:, :g.shape[1]] - g).max() <= 1e-3
+    # silence and a full-scale square wave (clamp edge cases)
+    for pcm in (np.zeros(16000, np.float32), np.sign(np.sin(np.arange(32000) * 0.05)).astype(np.float32)):
+        ref = ost.pcm_to_mel(pcm); st.pcm_to_mel(pcm)
+        assert np.abs(st.get_mel(ref.shape[1]) - ref).max() <= 1e-3
+    st.free(); ctx.free(); ost.close(); om.close()
+
+
+@pytest.mark.parametrize("arch", ["micro.en", "micro-v3"])
+def test_encoder_decoder_parity(wr, oracle, golden, model_path, arch):
+    path = model_path(arch)
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    ctx = wr.WhisperContext(path); st = ctx.create_state()
+    pcm = synth_pcm(7, 20 * 16000)
+    ost.pcm_to_mel(pcm); st.pcm_to_mel(pcm)
+    ref = ost.encode(0)
+    st.encode(0)
+    got = st.encoder_output()
+    err = np.abs(got - ref).max()
+    print(arch, "encoder max abs err", err, "ref std", ref.std())
+    assert err <= 3e-2, err                                   # fp16 activations through the stack; values are O(1)
+    assert np.abs(got[::50] - golden[f"{arch}_enc"]).max() <= 5e-2
+    for layer in range(om.n_text_layer):
+        k_ref, v_ref = ost.cross_kv(layer)
+        k, v = st.cross_kv(layer)
+        assert np.abs(k - k_ref).max() <= 3e-2 and np.abs(v - v_ref).max() <= 3e-2
+    toks = [int(t) for t in golden[f"{arch}_tokens"]]
+    lref = ost.decode(toks, 0, 0, logits_all=True)
+    lgot = st.decode_logits_all(toks, 0)
+    lerr = np.abs(lgot - lref).max()
+    print(arch, "logits max abs err", lerr, "std", lref.std())
+    assert lerr <= 3e-2, lerr
+    assert np.abs(lgot[:, ::97] - golden[f"{arch}_logits_sub"]).max() <= 5e-2
+    # incremental decode through the paged cache equals the batched pass
+    st.decode(toks[:4], 0)
+    inc = np.stack([st.decode([toks[i]], i) for i in range(4, 8)])
+    assert np.abs(inc - lgot[4:8]).max() <= 2e-3
+    st.free(); ctx.free(); ost.close(); om.close()
