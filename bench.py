@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RTFx (audio-seconds per wall-second) of Whisper large-v3-turbo batched
+transcription on MI355X, one independent engine per GPU, data-parallel by utterance.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the whole hot path (log-mel -> encoder -> cross-K/V -> greedy decode) over one batch
+of synthetic 30 s / 16 kHz utterances whose PCM is already resident in HBM. Weights are a seeded synthetic
+ggml file of the exact large-v3-turbo architecture (no checkpoint can be fetched here); with content-free
+audio and weights the natural transcript length is meaningless, so every utterance decodes exactly
+--tokens tokens (end-of-text masked before, forced at, that position).
+
+Rank 0 prints ONE JSON line carrying, besides the contract fields,
+  roofline     -- the dominant kernel class (encoder GEMMs, MFMA-bound): algorithmic flop / device time,
+                  measured with HIP events on the engine's stream inside the timed region;
+  cpu_baseline -- the CPU oracle (a port, not whisper.cpp) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (vendor figure without sparsity)
+
+
+def model_file(arch: str, seed: int = 0) -> str:
+    from handy_amd import ggml_file
+    d = os.environ.get("WMI_MODEL_DIR", "/tmp/wmi_models")
+    os.makedirs(d, exist_ok=True)
+    real = os.path.join(d, {"large-v3-turbo": "ggml-large-v3-turbo.bin"}.get(arch, f"ggml-{arch}.bin"))
+    if os.path.exists(real):
+        return real
+    p = os.path.join(d, f"synthetic-{arch}-s{seed}.bin")
+    if not os.path.exists(p):
+        tmp = p + f".{os.getpid()}.tmp"
+        ggml_file.write_synthetic_model(tmp, arch, seed=seed, decisive=2.0)
+        os.replace(tmp, p)
+    return p
+
+
+def cpu_baseline(path: str, tokens: int, budget_s: float = 30.0):
+    """The oracle (kind 'port': this repo's CPU restatement, not whisper.cpp) on one 30 s utterance:
+    log-mel + encoder on all host threads it is given, then as many forced decode steps as fit the budget."""
+    from handy_amd.synth import synth_pcm
+    from oracle import oracle as wo
+    wo.build()
+    om = wo.OracleModel(path)
+    st = wo.OracleState(om)
+    pcm = synth_pcm(0)
+    t0 = time.time()
+    st.pcm_to_mel(pcm)
+    t_mel = time.time() - t0
+    t0 = time.time()
+    st.encode(0)
+    t_enc = time.time() - t0
+    sot = om.special("sot")
+    prompt = [sot, sot + 1, om.special("transcribe"), om.special("not")] if om.n_vocab >= 51865 else [sot, om.special("not")]
+    t0 = time.time()
+    st.decode(prompt, 0)
+    n_done, pos = 0, len(prompt)
+    while n_done < tokens and (time.time() - t0) < max(2.0, budget_s - t_enc - t_mel):
+        st.decode([1000 + n_done], pos)
+        pos += 1
+        n_done += 1
+    t_dec_measured = time.time() - t0
+    t_dec = t_dec_measured * (tokens / max(n_done, 1))
+    total = t_mel + t_enc + t_dec
+    cores = wo.lib().wo_n_threads()
+    st.close(); om.close()
+    return {"value": 30.0 / total, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+            "sample": f"1 utterance x 30 s: mel {t_mel:.2f}s + encoder {t_enc:.2f}s measured, decode {n_done}/{tokens} tokens measured "
+                      f"({t_dec_measured:.2f}s) and scaled to {tokens}; OpenMP threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("WMI_BENCH_BATCH", "128")), help="utterances per GPU per step")
+    ap.add_argument("--tokens", type=int, default=128, help="decoded tokens per utterance")
+    ap.add_argument("--arch", default="large-v3-turbo")
+    ap.add_argument("--enc-chunk", type=int, default=int(os.environ.get("WMI_ENC_CHUNK", "16")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from handy_amd import whisper_rs as wr
+    from handy_amd.synth import synth_pcm
+
+    # rank 0 writes the synthetic model file once; the others wait for it
+    if rank == 0:
+        path = model_file(args.arch)
+    if world > 1:
+        dist.barrier()
+    path = model_file(args.arch)
+
+    ctx = wr.WhisperContext(path, wr.WhisperContextParameters(local_rank))
+    B = args.batch
+    st = ctx.create_batch_state(B, 1, args.enc_chunk)
+    st.set_force_tokens(args.tokens)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0)
+    fp.set_no_timestamps(True)
+    fp.set_language("en")
+
+    # synthetic PCM resident in HBM: a pool of 16 distinct utterances per rank, tiled to the batch
+    n_samp = 30 * 16000
+    pool = np.stack([synth_pcm(rank * 1000 + i, n_samp) for i in range(min(16, B))])
+    pcm_dev = torch.from_numpy(pool).to(dev)
+    pcm_dev = pcm_dev.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1)[:B].contiguous()
+    ptrs = [pcm_dev.data_ptr() + i * n_samp * 4 for i in range(B)]
+    ns = [n_samp] * B
+
+    def step():
+        st.full_batch_device(fp, ptrs, ns)
+        toks = np.full((B, args.tokens + 2), -1, dtype=np.int32)
+        for u in range(B):
+            t = st.batch_tokens(u)
+            toks[u, :len(t)] = t
+        if world > 1:       # the only collective on the path: gather the per-utterance token records
+            tt = torch.from_numpy(toks).to(dev)
+            out = [torch.empty_like(tt) for _ in range(world)] if rank == 0 else None
+            dist.gather(tt, out, dst=0)
+        return toks
+
+    for _ in range(args.warmup):
+        toks = step()
+    st.set_profiling(True)
+    st.reset_kernel_stats()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = st.kernel_stats()
+    st.set_profiling(False)
+    n_tok = int((toks >= 0).sum(axis=1).min())
+    assert n_tok == args.tokens + 1, f"decode produced {n_tok} tokens per utterance, expected {args.tokens + 1}"
+
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        audio_s = 30.0 * B * world * args.steps
+        g = stats["enc_gemm"]
+        achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        per_class = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                         "rate": (v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0} for k, v in stats.items()}
+        line = {
+            "metric": "RTFx (audio-sec/sec) whole node, Whisper large-v3-turbo", "value": audio_s / dt, "unit": "audio-sec/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"Whisper {args.arch} fp16 (synthetic ggml weights of the exact architecture), {B} x 30 s utterances per GPU per step, "
+                                   f"greedy, no_timestamps, {args.tokens} forced tokens per utterance, PCM resident in HBM",
+                       "utterances_per_gpu": B, "tokens_per_utterance": args.tokens, "enc_chunk": args.enc_chunk, "parallelism": f"dp{world} by utterance"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (encoder conv/QKV/out/MLP/cross-KV GEMMs)", "achieved": achieved,
+                         "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": g["ms"] / max(g["launches"], 1), "launches": g["launches"]},
+            "kernel_classes": per_class,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(path, args.tokens)
+            except Exception as e:      # the baseline is reported, never required for the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "audio-sec/sec", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(line))
+    st.free(); ctx.free()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
