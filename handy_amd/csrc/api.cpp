@@ -376,7 +376,7 @@ void wmi_reset_kernel_stats(struct whisper_state *s) { if (Engine *e = ENG(s)) e
 int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C) {
     WMI_TRY
     if (M <= 0 || N % 64 || K % 64 || !A || !W || !C) return -1;
-    const int Mp = round_up(M, 128);
+    const int Mp = round_up(M, 256);
     std::vector<f16> a((size_t)Mp * K, (f16)0.0f), w((size_t)N * K);
     for (size_t i = 0; i < (size_t)M * K; i++) a[i] = (f16)A[i];
     for (size_t i = 0; i < (size_t)N * K; i++) w[i] = (f16)W[i];
@@ -387,6 +387,39 @@ int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C
         gemm_f32(da, K, dw, K, M, N, K, dc, N, nullptr, nullptr) && hipDeviceSynchronize() == hipSuccess &&
         hipMemcpy(C, dc, (size_t)M * N * 4, hipMemcpyDeviceToHost) == hipSuccess)
         rc = 0;
+    (void)hipFree(da); (void)hipFree(dw); (void)hipFree(dc);
+    return rc;
+    WMI_CATCH(-1)
+}
+
+void wmi_debug_set_tile_group(int rows) { if (rows >= 1) wmi::g_tile_group_rows = rows; }
+
+// GEMM tile-shape harness: random fp16 operands, `iters` launches of one variant, average ms by HIP events.
+int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {
+    WMI_TRY
+    if (M <= 0 || N % 256 || K % 64 || iters <= 0 || !ms_out) return -1;
+    const size_t Mp = round_up(M, 256);
+    std::vector<f16> a(Mp * K), w((size_t)N * K);
+    uint32_t x = 12345u;
+    auto rnd = [&]() { x = x * 1664525u + 1013904223u; return (float)((int)(x >> 9) % 2001 - 1000) * 1e-3f; };
+    for (auto &v : a) v = (f16)rnd();
+    for (auto &v : w) v = (f16)rnd();
+    f16 *da = nullptr, *dw = nullptr, *dc = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess && hipMalloc(&dc, Mp * N * 2 + 4096) == hipSuccess &&
+        hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+        hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; i++) ok = gemm_variant(variant, da, K, dw, K, M, N, K, dc, N, nullptr);
+        ok = ok && hipDeviceSynchronize() == hipSuccess && hipEventRecord(e0, nullptr) == hipSuccess;
+        for (int i = 0; i < iters && ok; i++) ok = gemm_variant(variant, da, K, dw, K, M, N, K, dc, N, nullptr);
+        ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+        float ms = 0;
+        if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { *ms_out = ms / iters; rc = 0; }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(da); (void)hipFree(dw); (void)hipFree(dc);
     return rc;
     WMI_CATCH(-1)

@@ -58,7 +58,7 @@ Engine::~Engine() {
     (void)hipSetDevice(model->device);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (DevBuf *b : {&pcm_, &mel_raw_, &mel_max_, &mel_utt_dev_, &mel_norm_tmp_, &melT_, &h1_, &x_, &xn_, &q_, &k_, &vt_, &att_, &hid_, &enc16_, &enc32_,
-                      &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_})
+                      &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_, &sample_ws_})
         b->release();
     meta_host_.release(); out_host_.release(); probs_host_.release();
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -67,10 +67,10 @@ Engine::~Engine() {
 
 bool Engine::alloc_workspaces() {
     const int E = enc_chunk_, T = T_full_, d = d_;
-    const size_t M1 = (size_t)E * (2 * T + 2), M2p = round_up(E * (T + 1), 128), Mp = round_up(E * T, 128);
+    const size_t M1 = (size_t)E * (2 * T + 2), M2p = round_up(E * (T + 1), 256), Mp = round_up(E * T, 256);
     bool ok = true;
-    ok &= melT_.ensure(((M1 + 256) * n_mel_ + 1024) * sizeof(f16));
-    ok &= h1_.ensure(((std::max(M1 + 2, 2 * M2p + 8) + 128) * d) * sizeof(f16));
+    ok &= melT_.ensure(((M1 + 512) * n_mel_ + 1024) * sizeof(f16));
+    ok &= h1_.ensure(((std::max(M1 + 2, 2 * M2p + 8) + 256) * d) * sizeof(f16));
     ok &= x_.ensure(Mp * d * sizeof(float));
     ok &= xn_.ensure(Mp * d * sizeof(f16));
     ok &= att_.ensure(Mp * d * sizeof(f16));
@@ -96,11 +96,12 @@ bool Engine::alloc_workspaces() {
     page_ref_.assign(n_pages_, 0);
     free_pages_.clear();
     for (int i = n_pages_ - 1; i >= 1; i--) free_pages_.push_back(i);       // page 0 stays unused: block tables are zero-filled
-    lrows_cap_ = round_up(std::max(max_seqs, 8), 128);
+    lrows_cap_ = round_up(std::max(max_seqs, 8), 256);
     ok &= dxl_.ensure((size_t)lrows_cap_ * d * sizeof(f16));
     ok &= logits_.ensure((size_t)lrows_cap_ * Vp_ * sizeof(float));
     ok &= out_dev_.ensure((size_t)lrows_cap_ * (sizeof(SampleOut) + 8 * sizeof(TopkOut)));
     ok &= out_host_.ensure((size_t)lrows_cap_ * (sizeof(SampleOut) + 8 * sizeof(TopkOut)));
+    ok &= sample_ws_.ensure(sample_workspace_bytes(lrows_cap_));
     logits_host_.assign(V_, 0.0f);
     ok &= ensure_rows(std::max(128, max_seqs));
     return ok;
@@ -108,7 +109,7 @@ bool Engine::alloc_workspaces() {
 
 bool Engine::ensure_rows(int rows) {
     if (rows <= rows_cap_) return true;
-    const size_t R = round_up(rows, 128);
+    const size_t R = round_up(rows, 256);
     bool ok = dx_.ensure(R * d_ * sizeof(float)) && dxn_.ensure(R * d_ * sizeof(f16)) && dq_.ensure(R * d_ * sizeof(f16)) &&
               datt_.ensure(R * d_ * sizeof(f16)) && dhid_.ensure(R * 4 * d_ * sizeof(f16));
     const size_t meta = R * sizeof(DecRow) + (size_t)lrows_cap_ * (sizeof(SampleRow) + sizeof(int) * (kMaxPagesPerSeq + 1)) + R * sizeof(int2) + 4096;
@@ -257,7 +258,7 @@ bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<in
         PROF(WMI_K_ENC_GEMM, 2.0 * M * 4 * d * d, gemm_residual(hid_.as<f16>(), 4 * d, L.fc2, 4 * d, M, d, 4 * d, x_.as<float>(), d, L.b2, stream_));
     }
     float *e32 = nullptr;
-    if (want_f32) { if (!enc32_.ensure((size_t)round_up(M, 128) * d * sizeof(float))) return false; e32 = enc32_.as<float>(); }
+    if (want_f32) { if (!enc32_.ensure((size_t)round_up(M, 256) * d * sizeof(float))) return false; e32 = enc32_.as<float>(); }
     PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(x_.as<float>(), model->ln_post_w, model->ln_post_b, enc16_.as<f16>(), e32, M, d, nullptr, stream_));
     PROF(WMI_K_ENC_GEMM, 2.0 * M * (2.0 * Ld_ * d) * d,
          gemm_cross_kv(enc16_.as<f16>(), model->xkv_w, M, d, H_, T, Tp, Ld_, ckv_.as<f16>(), model->xkv_b, slots_dev_.as<int>(), stream_));
@@ -382,8 +383,10 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         if (any_probs && (!probs_.ensure((size_t)lrows_cap_ * V_ * sizeof(float), false) || !probs_host_.ensure((size_t)lrows_cap_ * V_ * sizeof(float)))) return false;
         SampleOut *d_out = out_dev_.as<SampleOut>();
         TopkOut *d_topk = (TopkOut *)(out_dev_.as<char>() + sizeof(SampleOut) * lrows_cap_);
+        bool any_extra = any_probs;
+        for (const SampleRow &s : srows) any_extra |= s.topk > 0;
         PROF(WMI_K_DEC_OTHER, 8.0 * L * V_, sample_rows(logits_.as<float>(), Vp_, L, d_srow, model->vocab_ids(), model->nst_bitmap, d_out, d_topk, 8,
-                                                       any_probs ? probs_.as<float>() : nullptr, stream_));
+                                                       any_probs ? probs_.as<float>() : nullptr, any_extra, sample_ws_.p, stream_));
         WMI_HIP_OK(hipMemcpyAsync(out_host_.p, out_dev_.p, sizeof(SampleOut) * lrows_cap_ + sizeof(TopkOut) * 8 * (size_t)L, hipMemcpyDeviceToHost, stream_));
         if (any_probs) WMI_HIP_OK(hipMemcpyAsync(probs_host_.p, probs_.p, sizeof(float) * (size_t)L * V_, hipMemcpyDeviceToHost, stream_));
     }

@@ -139,7 +139,7 @@ private:
     int n_pages_ = 0;
     long layer_stride_ = 0;
     std::vector<int> free_pages_, page_ref_;
-    DevBuf meta_dev_, out_dev_;
+    DevBuf meta_dev_, out_dev_, sample_ws_;
     PinnedBuf meta_host_, out_host_, probs_host_;
     std::vector<float> logits_host_;
     Decoder ll_dec_;                 // sequence used by whisper_decode()

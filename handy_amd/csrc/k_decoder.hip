@@ -140,11 +140,19 @@ bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, int M
 }
 
 // ------------------------------------------------------------------------------------------ logits rules + selection
-// One workgroup per logit row. Restates whisper_process_logits + whisper_sample_token(best):
-// suppression rules, timestamp pairing / monotonicity / initial bound, log-softmax, the
-// "timestamp mass beats every text token" rule, then argmax (lowest id on ties) and timestamp
-// statistics, all with wavefront reductions. Pass 1 writes the masked logits back in place so the
-// later passes (sum, optional top-k, optional probabilities) are plain reads that hit in L2.
+// Restates whisper_process_logits + whisper_sample_token(best): suppression rules, timestamp pairing /
+// monotonicity / initial bound, log-softmax, the "timestamp mass beats every text token" rule, then
+// argmax (lowest id on ties) and timestamp statistics, with wavefront reductions.
+// A row of ~52k logits is split over kSampleSplits workgroups so that a small batch still fills the chip:
+//   1. sample_partial_kernel  masks its slice in place (later passes are plain reads that hit in L2) and
+//      emits per-slice maxima (text / timestamp, with index) and exp-sums relative to the slice maximum;
+//   2. sample_final_kernel    one wave per row folds the slices, applies the timestamp-mass rule, selects;
+//   3. sample_extra_kernel    only for rows that asked for it: probabilities (host-side draws at T > 0) and the
+//      per-slice top-k candidates;  4. topk_merge_kernel folds those into the row's k most probable tokens.
+constexpr int kSampleSplits = 16;
+constexpr int kSampleChunk = 3328;              // 13 x 256; 16 x 3328 >= 52000
+constexpr int kSamplePer = kSampleChunk / 256;
+
 struct ArgMax { float v; int i; };
 __device__ __forceinline__ ArgMax amax2(ArgMax a, ArgMax b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
 __device__ __forceinline__ ArgMax wave_amax(ArgMax a) {
@@ -152,7 +160,6 @@ __device__ __forceinline__ ArgMax wave_amax(ArgMax a) {
     return a;
 }
 __device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-
 __device__ ArgMax block_amax(ArgMax a, ArgMax *sh) {
     a = wave_amax(a);
     __syncthreads();
@@ -170,100 +177,161 @@ __device__ float block_sum(float v, float *sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__global__ __launch_bounds__(256) void sample_rows_kernel(float *__restrict__ logits, long ld, const SampleRow *__restrict__ srow, VocabIds vi,
-                                                          const unsigned *__restrict__ nst_bitmap, SampleOut *__restrict__ out,
-                                                          TopkOut *__restrict__ topk, int topk_stride, float *__restrict__ probs) {
+struct SamplePartial { float mt_v; int mt_i; float ms_v; int ms_i; float m, st, ss; int pad; };
+
+__global__ __launch_bounds__(256) void sample_partial_kernel(float *__restrict__ logits, long ld, const SampleRow *__restrict__ srow, VocabIds vi,
+                                                             const unsigned *__restrict__ nst_bitmap, SamplePartial *__restrict__ part) {
     __shared__ ArgMax sh_a[4];
     __shared__ float sh_f[4];
-    const int r = blockIdx.x, tid = threadIdx.x, V = vi.n_vocab;
+    const int s = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, V = vi.n_vocab;
     const SampleRow sr = srow[r];
     float *lg = logits + (long)r * ld;
     const int fl = sr.flags;
     const bool is_initial = fl & 1, last_ts = fl & 2, pen_ts = fl & 4, has_ts = fl & 8, sup_blank = fl & 16, no_ts = fl & 32,
                sup_nst = fl & 64, tdrz = fl & 128, raw = fl & 256;
-    const float inv_t = sr.temperature > 0.0f ? 1.0f / sr.temperature : 1.0f;
-    ArgMax mt = {-INFINITY, 0x7fffffff}, ms = {-INFINITY, 0x7fffffff};      // text / timestamp maxima
-    for (int i = tid; i < V; i += 256) {
-        float v = lg[i];
-        if (sr.temperature > 0.0f) v = v / sr.temperature;
-        (void)inv_t;
-        if (!raw) {
-            bool kill = false;
-            if (sup_blank && is_initial && (i == vi.eot || i == vi.space)) kill = true;
-            if (i == vi.tok_not || i == vi.sot || i == vi.nosp || i == vi.translate || i == vi.transcribe || i == vi.prev) kill = true;
-            if (i == vi.solm && !tdrz) kill = true;
-            if (no_ts && i >= vi.beg) kill = true;
-            if (i > vi.sot && i <= vi.sot + 100) kill = true;                       // language tokens
-            if (sup_nst && ((nst_bitmap[i >> 5] >> (i & 31)) & 1)) kill = true;
-            if (sr.force_n > 0) {
-                if (sr.n_sampled < sr.force_n) { if (i == vi.eot) kill = true; }
-                else { if (i != vi.eot) kill = true; else { kill = false; v = 0.0f; } }
+    ArgMax mt = {-INFINITY, 0x7fffffff}, ms = {-INFINITY, 0x7fffffff};
+    float val[kSamplePer];
+#pragma unroll
+    for (int k = 0; k < kSamplePer; k++) {
+        const int i = s * kSampleChunk + k * 256 + tid;
+        float v = -INFINITY;
+        if (i < V) {
+            v = lg[i];
+            if (sr.temperature > 0.0f) v = v / sr.temperature;
+            if (!raw) {
+                bool kill = false;
+                if (sup_blank && is_initial && (i == vi.eot || i == vi.space)) kill = true;
+                if (i == vi.tok_not || i == vi.sot || i == vi.nosp || i == vi.translate || i == vi.transcribe || i == vi.prev) kill = true;
+                if (i == vi.solm && !tdrz) kill = true;
+                if (no_ts && i >= vi.beg) kill = true;
+                if (i > vi.sot && i <= vi.sot + 100) kill = true;                       // language tokens
+                if (sup_nst && ((nst_bitmap[i >> 5] >> (i & 31)) & 1)) kill = true;
+                if (sr.force_n > 0) {
+                    if (sr.n_sampled < sr.force_n) { if (i == vi.eot) kill = true; }
+                    else { if (i != vi.eot) kill = true; else { kill = false; v = 0.0f; } }
+                }
+                if (last_ts) { if (pen_ts) { if (i >= vi.beg) kill = true; } else if (i < vi.eot) kill = true; }
+                if (is_initial && sr.max_initial >= 0 && i > vi.beg + sr.max_initial) kill = true;
+                if (has_ts && i >= vi.beg && i < vi.beg + sr.ts_min) kill = true;
+                if (kill) v = -INFINITY;
+                lg[i] = v;
             }
-            if (last_ts) { if (pen_ts) { if (i >= vi.beg) kill = true; } else if (i < vi.eot) kill = true; }
-            if (is_initial && sr.max_initial >= 0 && i > vi.beg + sr.max_initial) kill = true;
-            if (has_ts && i >= vi.beg && i < vi.beg + sr.ts_min) kill = true;
-            if (kill) v = -INFINITY;
-            lg[i] = v;
+            if (i < vi.beg) { if (v > mt.v) { mt.v = v; mt.i = i; } }
+            else if (v > ms.v) { ms.v = v; ms.i = i; }
         }
-        if (i < vi.beg) { if (v > mt.v) { mt.v = v; mt.i = i; } }
-        else if (v > ms.v) { ms.v = v; ms.i = i; }
+        val[k] = v;
     }
     mt = block_amax(mt, sh_a);
     ms = block_amax(ms, sh_a);
-    const float mx = fmaxf(mt.v, ms.v);
-    float st_ = 0.0f, ss_ = 0.0f;
-    for (int i = tid; i < V; i += 256) {
-        const float v = lg[i];
-        if (v > -INFINITY) { const float e = __expf(v - mx); if (i < vi.beg) st_ += e; else ss_ += e; }
+    const float m = fmaxf(mt.v, ms.v);
+    float st = 0.0f, ss = 0.0f;
+    if (m > -INFINITY) {
+#pragma unroll
+        for (int k = 0; k < kSamplePer; k++) {
+            const int i = s * kSampleChunk + k * 256 + tid;
+            if (val[k] > -INFINITY) { const float e = __expf(val[k] - m); if (i < vi.beg) st += e; else ss += e; }
+        }
     }
-    st_ = block_sum(st_, sh_f);
-    ss_ = block_sum(ss_, sh_f);
-    const float lse = logf(st_ + ss_) + mx;
-    // timestamp mass rule: log(sum_ts p) > max text logprob  =>  only timestamps remain
-    const float ts_lp = ss_ > 0.0f ? logf(ss_) + mx - lse : -INFINITY;
+    st = block_sum(st, sh_f);
+    ss = block_sum(ss, sh_f);
+    if (tid == 0) part[(long)r * kSampleSplits + s] = SamplePartial{mt.v, mt.i, ms.v, ms.i, m, st, ss, 0};
+}
+
+__global__ __launch_bounds__(64) void sample_final_kernel(const SamplePartial *__restrict__ part, const SampleRow *__restrict__ srow, VocabIds vi, SampleOut *__restrict__ out) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    SamplePartial p{-INFINITY, 0x7fffffff, -INFINITY, 0x7fffffff, -INFINITY, 0.0f, 0.0f, 0};
+    if (lane < kSampleSplits) p = part[(long)r * kSampleSplits + lane];
+    const ArgMax mt = wave_amax(ArgMax{p.mt_v, p.mt_i}), ms = wave_amax(ArgMax{p.ms_v, p.ms_i});
+    const float mx = fmaxf(mt.v, ms.v);
+    const float f = p.m > -INFINITY ? __expf(p.m - mx) : 0.0f;
+    const float st = wave_sum(p.st * f), ss = wave_sum(p.ss * f);
+    if (lane != 0) return;
+    const bool raw = srow[r].flags & 256;
+    const float lse = logf(st + ss) + mx;
+    const float ts_lp = ss > 0.0f ? logf(ss) + mx - lse : -INFINITY;      // log of the total timestamp probability
     const bool ts_wins = !raw && ts_lp > mt.v - lse;
     ArgMax best = ts_wins ? ms : amax2(mt, ms);
     if (best.i == 0x7fffffff) best.i = 0;
-    if (tid == 0) {
-        SampleOut o;
-        o.id = best.i; o.plog = best.v - lse; o.p = __expf(o.plog); o.lse = lse; o.pad = ts_wins ? 1 : 0;
-        const float sum_ts = ss_ > 0.0f ? __expf(logf(ss_) + mx - lse) : 0.0f;
-        const float max_ts = ms.v > -INFINITY ? __expf(ms.v - lse) : 0.0f;
-        o.tid = max_ts > 0.0f ? ms.i : vi.beg;
-        o.pt = max_ts / (sum_ts + 1e-10f); o.ptsum = sum_ts;
-        if (o.id >= vi.beg) { o.tid = o.id; o.pt = o.p; }
-        out[r] = o;
+    SampleOut o;
+    o.id = best.i; o.plog = best.v - lse; o.p = __expf(o.plog); o.lse = lse; o.pad = ts_wins ? 1 : 0;
+    const float sum_ts = ss > 0.0f ? __expf(ts_lp) : 0.0f;
+    const float max_ts = ms.v > -INFINITY ? __expf(ms.v - lse) : 0.0f;
+    o.tid = max_ts > 0.0f ? ms.i : vi.beg;
+    o.pt = max_ts / (sum_ts + 1e-10f); o.ptsum = sum_ts;
+    if (o.id >= vi.beg) { o.tid = o.id; o.pt = o.p; }
+    out[r] = o;
+}
+
+struct TopkCand { float v; int i; };
+
+__global__ __launch_bounds__(256) void sample_extra_kernel(const float *__restrict__ logits, long ld, const SampleRow *__restrict__ srow, VocabIds vi,
+                                                           const SampleOut *__restrict__ out, float *__restrict__ probs, TopkCand *__restrict__ cand) {
+    __shared__ ArgMax sh_a[4];
+    const int s = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, V = vi.n_vocab;
+    const SampleRow sr = srow[r];
+    if (!sr.want_probs && sr.topk <= 0) return;
+    const SampleOut o = out[r];
+    const bool ts_wins = o.pad != 0;
+    const float *lg = logits + (long)r * ld;
+    float val[kSamplePer];
+#pragma unroll
+    for (int k = 0; k < kSamplePer; k++) {
+        const int i = s * kSampleChunk + k * 256 + tid;
+        float v = -INFINITY;
+        if (i < V) { v = lg[i]; if (ts_wins && i < vi.beg) v = -INFINITY; }
+        val[k] = v;
+        if (probs && sr.want_probs && i < V) probs[(long)r * V + i] = v == -INFINITY ? 0.0f : __expf(v - o.lse);
     }
-    if (probs && sr.want_probs) {
-        float *pr = probs + (long)r * V;
-        for (int i = tid; i < V; i += 256) {
-            const float v = lg[i];
-            pr[i] = (v == -INFINITY || (ts_wins && i < vi.beg)) ? 0.0f : __expf(v - lse);
-        }
-    }
-    if (topk && sr.topk > 0) {
-        int chosen[8];
-        for (int k = 0; k < sr.topk && k < 8; k++) {
+    if (cand && sr.topk > 0) {
+        for (int t = 0; t < sr.topk && t < 8; t++) {
             ArgMax a = {-INFINITY, 0x7fffffff};
-            for (int i = (ts_wins ? vi.beg : 0) + tid; i < V; i += 256) {
-                const float v = lg[i];
-                bool used = false;
-                for (int u = 0; u < k; u++) used |= chosen[u] == i;
-                if (!used && v > a.v) { a.v = v; a.i = i; }
-            }
+#pragma unroll
+            for (int k = 0; k < kSamplePer; k++) { const int i = s * kSampleChunk + k * 256 + tid; if (val[k] > a.v) { a.v = val[k]; a.i = i; } }
             a = block_amax(a, sh_a);
-            chosen[k] = a.i;
-            if (tid == 0) {
-                TopkOut t; t.id = a.i == 0x7fffffff ? -1 : a.i; t.plog = a.v - lse; t.p = a.v > -INFINITY ? __expf(t.plog) : 0.0f; t.pad = 0;
-                topk[(long)r * topk_stride + k] = t;
-            }
+#pragma unroll
+            for (int k = 0; k < kSamplePer; k++) if (s * kSampleChunk + k * 256 + tid == a.i) val[k] = -INFINITY;
+            if (tid == 0) cand[((long)r * kSampleSplits + s) * 8 + t] = TopkCand{a.v, a.i};
         }
     }
 }
+
+__global__ __launch_bounds__(128) void topk_merge_kernel(const TopkCand *__restrict__ cand, const SampleRow *__restrict__ srow, const SampleOut *__restrict__ out,
+                                                         TopkOut *__restrict__ topk, int topk_stride) {
+    __shared__ ArgMax sh[2];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int k = min(srow[r].topk, 8);
+    if (k <= 0) return;
+    const float lse = out[r].lse;
+    TopkCand c = cand[(long)r * kSampleSplits * 8 + tid];           // 16 slices x 8 candidates
+    if ((tid & 7) >= k) c = TopkCand{-INFINITY, 0x7fffffff};
+    for (int t = 0; t < k; t++) {
+        ArgMax a = wave_amax(ArgMax{c.v, c.i});
+        __syncthreads();
+        if ((tid & 63) == 0) sh[tid >> 6] = a;
+        __syncthreads();
+        a = amax2(sh[0], sh[1]);
+        if (c.i == a.i) c.v = -INFINITY;
+        if (tid == 0) {
+            TopkOut o; o.id = (a.v == -INFINITY || a.i == 0x7fffffff) ? -1 : a.i; o.plog = a.v - lse; o.p = a.v > -INFINITY ? __expf(o.plog) : 0.0f; o.pad = 0;
+            topk[(long)r * topk_stride + t] = o;
+        }
+    }
+}
+
+size_t sample_workspace_bytes(int max_rows) { return (size_t)max_rows * kSampleSplits * (sizeof(SamplePartial) + 8 * sizeof(TopkCand)); }
+
 bool sample_rows(float *logits, long ld, int R, const SampleRow *srow, const VocabIds &vi, const unsigned *nst_bitmap,
-                 SampleOut *out, TopkOut *topk, int topk_stride, float *probs, hipStream_t st) {
+                 SampleOut *out, TopkOut *topk, int topk_stride, float *probs, bool any_extra, void *workspace, hipStream_t st) {
     if (R <= 0) return true;
-    hipLaunchKernelGGL(sample_rows_kernel, dim3(R), dim3(256), 0, st, logits, ld, srow, vi, nst_bitmap, out, topk, topk_stride, probs);
+    if (vi.n_vocab > kSampleSplits * kSampleChunk) { log_msg(2, "sample_rows: vocabulary of %d exceeds the kernel's slicing\n", vi.n_vocab); return false; }
+    SamplePartial *part = (SamplePartial *)workspace;
+    TopkCand *cand = (TopkCand *)(part + (size_t)R * kSampleSplits);
+    hipLaunchKernelGGL(sample_partial_kernel, dim3(kSampleSplits, R), dim3(256), 0, st, logits, ld, srow, vi, nst_bitmap, part);
+    hipLaunchKernelGGL(sample_final_kernel, dim3(R), dim3(64), 0, st, part, srow, vi, out);
+    if (any_extra) {
+        hipLaunchKernelGGL(sample_extra_kernel, dim3(kSampleSplits, R), dim3(256), 0, st, logits, ld, srow, vi, out, probs, cand);
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(R), dim3(128), 0, st, cand, srow, out, topk, topk_stride);
+    }
     return hipGetLastError() == hipSuccess;
 }
 

@@ -1,11 +1,11 @@
 // fp16 x fp16 -> fp32 "NT" GEMM for gfx950:  C[m][n] = sum_k Act[m][k] * W[n][k]   (+ fused epilogue)
 //
 // Both operands are K-contiguous (activations row-major, weights stored [out][in] as in the ggml
-// file), so every MFMA fragment is one 16-byte run along K. Structure per workgroup (256 threads,
-// 4 waves in a 2x2 arrangement):
+// file), so every MFMA fragment is one 16-byte run along K. Structure per workgroup (8 waves as 4x2
+// on a 256x128 tile, or 4 waves as 2x2 on a 64x64 tile):
 //   * BM x 64 activation tile and BN x 64 weight tile per K-step, copied global->LDS with the
-//     16-byte LDS-DMA form (__builtin_amdgcn_global_load_lds); two LDS stages, the copy of step
-//     k+1 is in flight while step k is multiplied; one barrier per K-step.
+//     16-byte LDS-DMA form (__builtin_amdgcn_global_load_lds); 3-4 LDS stages so that one or two
+//     whole K-steps of loads stay in flight across each barrier; one barrier per K-step.
 //   * LDS rows are 128 B; 16-byte chunk c of row r sits in slot c ^ (r & 7). The DMA writes LDS
 //     linearly (wave base + lane*16), so the permutation is applied to each lane's SOURCE address
 //     and again to the fragment read address: ds_read_b128 is then conflict-free.
@@ -22,17 +22,15 @@ namespace wmi {
 constexpr int BK = 64;             // halfs per K-step (128 B rows in LDS)
 
 __device__ __forceinline__ float gelu_f16_dev(float x) {
-    // tanh-form GELU evaluated on the f16-rounded input and rounded to f16 (the values ggml's
-    // f16 lookup table holds); saturates like the table's guard: x<=-10 -> 0, x>=10 -> x.
-    if (x <= -10.0f) return 0.0f;
-    if (x >= 10.0f) return x;
-    float h = (float)(f16)x;
-    float u = 0.79788456080286535587989211986876f * h * (1.0f + 0.044715f * h * h);
-    // tanh(u) = 1 - 2/(exp(2u)+1)
-    float e = __expf(2.0f * u);
-    float t = 1.0f - 2.0f / (e + 1.0f);
-    float g = 0.5f * h * (1.0f + t);
-    return (float)(f16)g;
+    // tanh-form GELU evaluated on the f16-rounded input and rounded to f16 (the values ggml's f16
+    // lookup table holds), with the table's guards: x <= -10 -> 0, x >= 10 -> x.
+    // 0.5 h (1 + tanh u) = h (1 - 1/(exp(2u) + 1)); exp and reciprocal are the hardware approximations,
+    // whose error (~1 ulp of f32) disappears in the rounding to f16.
+    const float h = (float)(f16)x;
+    const float u = 0.79788456080286535587989211986876f * h * (1.0f + 0.044715f * h * h);
+    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);          // exp(2u)
+    const float g = (float)(f16)(h - h * __builtin_amdgcn_rcpf(e + 1.0f));
+    return x >= 10.0f ? x : (x <= -10.0f ? 0.0f : g);
 }
 
 // ------------------------------------------------------------------------------------------ epilogues
@@ -141,23 +139,41 @@ struct EpiDecQKV {         // q -> qbuf[m][d] * 1/8 ; k,v -> paged cache [page][
 };
 
 // ------------------------------------------------------------------------------------------ kernel
-template <int BM, int BN, class Epi>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
-                                                      int M, int N, int K, Epi epi) {
+// Workgroup id -> output tile. Physical ids p, p+8, ... share an XCD (one private L2 each): every XCD
+// gets a contiguous run of logical ids, and logical ids walk the tile grid in groups of 8 tile rows x
+// all tile columns, column-major inside a group, so the ~32 tiles an XCD works on at one time form an
+// 8 x 4 patch that shares 8 activation panels and 4 weight panels through that L2.
+int g_tile_group_rows = 8;     // tile rows per group (harness knob; 8 is the shipped value)
+
+__device__ __forceinline__ void tile_coords(int p, int nbm, int nbn, int GM, int &bm, int &bn) {
+    const int nblk = nbm * nbn;
+    const int q = nblk >> 3, r = nblk & 7, x = p & 7, i = p >> 3;
+    const int l = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    const int gsz = GM * nbn, gid = l / gsz, first = gid * GM, rows = min(nbm - first, GM), w = l - gid * gsz;
+    bn = w / rows;
+    bm = first + (w - bn * rows);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BM x BN output tile, WM x WN waves (each owns a (BM/WM) x (BN/WN) sub-tile), NST LDS stages.
+// Stage s+NST-1 is issued while stage s is multiplied, so NST-2 whole stages stay in flight across
+// each barrier: the wait before the barrier is a COUNTED vmcnt (never 0 in the steady state) and the
+// barrier is the raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
+template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
+                                                                int M, int N, int K, int gm, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int TM = BM / 32, TN = BN / 32;     // 16x16 tiles per wave along m and n
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;     // 16x16 tiles per wave along m and n
+    constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW, LPS = LA + LB;   // LDS-DMA instructions per wave per stage
+    static_assert(LA >= 1 && LB >= 1, "tile too small for the wave count");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // XCD-aware remap: physical ids p, p+8, ... share an XCD; give each XCD a contiguous run of logical tiles
-    const int nbn = N / BN, nbm = (M + BM - 1) / BM, nblk = nbm * nbn;
-    int p = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, x = p & 7, i = p >> 3;
-        p = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-    }
-    const int bm = p / nbn, bn = p - bm * nbn;
+    int bm, bn;
+    tile_coords(blockIdx.x, (M + BM - 1) / BM, N / BN, gm, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
 
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -167,83 +183,263 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const f16 *__restrict__ A,
 
     // --- staging: one LDS-DMA wave-instruction moves 8 rows x 128 B
     const int srow = lane >> 3, sslot = lane & 7;
+    const f16 *a_src = A + (long)(m0 + wave * 8 + srow) * lda + ((sslot ^ srow) << 3);      // (row & 7) == srow for every piece
+    const f16 *w_src = W + (long)(n0 + wave * 8 + srow) * ldw + ((sslot ^ srow) << 3);
     auto stage = [&](int kt, int buf) {
-        char *base = smem + buf * STAGE;
+        char *base = smem + buf * STAGE + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < BM / 32; i++) {
-            const int r0 = (i * 4 + wave) * 8, row = r0 + srow, chunk = sslot ^ (row & 7);
-            const f16 *src = A + (long)(m0 + row) * lda + (long)kt * BK + chunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(base + r0 * 128), 16, 0, 0);
-        }
+        for (int i = 0; i < LA; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src + (long)i * NW * 8 * lda + (long)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(base + i * NW * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < BN / 32; i++) {
-            const int r0 = (i * 4 + wave) * 8, row = r0 + srow, chunk = sslot ^ (row & 7);
-            const f16 *src = W + (long)(n0 + row) * ldw + (long)kt * BK + chunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(base + A_BYTES + r0 * 128), 16, 0, 0);
-        }
+        for (int i = 0; i < LB; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_src + (long)i * NW * 8 * ldw + (long)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(base + A_BYTES + i * NW * 1024), 16, 0, 0);
     };
 
+    auto stage_piece = [&](int kt, int buf, int i, bool is_a) {
+        char *base = smem + buf * STAGE + wave * 1024;
+        if (is_a)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src + (long)i * NW * 8 * lda + (long)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(base + i * NW * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_src + (long)i * NW * 8 * ldw + (long)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(base + A_BYTES + i * NW * 1024), 16, 0, 0);
+    };
     const int nk = K / BK;
-    stage(0, 0);
+#pragma unroll
+    for (int s = 0; s < NST - 1; s++)
+        if (s < nk) stage(s, s);
     const int fr = lane & 15, fq = lane >> 4;
+    int buf = 0, nbuf = NST - 1;       // buffer being multiplied / buffer the next stage goes to
     for (int kt = 0; kt < nk; kt++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char *sa = smem + (kt & 1) * STAGE, *sb = sa + A_BYTES;
+        // stage kt has landed once at most min(NST-2, nk-1-kt) younger stages are still outstanding
+        const int younger = nk - 1 - kt;
+        if (NST >= 4 && younger >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LPS>();
+        else if (NST >= 3 && younger >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const bool more = kt + NST - 1 < nk;
+        if ((ABL & 1) == 0 && (ABL & 8) == 0 && more) stage(kt + NST - 1, nbuf);      // ABL bits: ablation builds of the harness only
+        const char *sa = smem + ((ABL & 1) ? 0 : buf) * STAGE, *sb = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             f16x8 fa[TM], fw[TN];
+            if ((ABL & 2) == 0 || kt == 0) {
 #pragma unroll
-            for (int j = 0; j < TM; j++) {
-                const int row = wr * (BM / 2) + j * 16 + fr;
-                fa[j] = *(const f16x8 *)(sa + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+                for (int j = 0; j < TM; j++) {
+                    const int row = wr * (BM / WM) + j * 16 + fr;
+                    fa[j] = *(const f16x8 *)(sa + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN; i++) {
+                    const int row = wc * (BN / WN) + i * 16 + fr;
+                    fw[i] = *(const f16x8 *)(sb + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+                }
             }
+            if (ABL & 4) {
 #pragma unroll
-            for (int i = 0; i < TN; i++) {
-                const int row = wc * (BN / 2) + i * 16 + fr;
-                fw[i] = *(const f16x8 *)(sb + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+                for (int j = 0; j < TM; j++) asm volatile("" ::"v"(fa[j]));
+#pragma unroll
+                for (int i = 0; i < TN; i++) asm volatile("" ::"v"(fw[i]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < TN; i++) {
+                    if ((ABL & 8) && more) {          // spread the LDS-DMA issue over the MFMA groups
+                        constexpr int per = (LPS + 2 * TN - 1) / (2 * TN);
+#pragma unroll
+                        for (int u = 0; u < per; u++) {
+                            const int li = (ks * TN + i) * per + u;
+                            if (li < LA) stage_piece(kt + NST - 1, nbuf, li, true);
+                            else if (li < LPS) stage_piece(kt + NST - 1, nbuf, li - LA, false);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TM; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+                    if (ABL & 8) __builtin_amdgcn_sched_barrier(0);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < TN; i++)
-#pragma unroll
-                for (int j = 0; j < TM; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
         }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
 #pragma unroll
     for (int i = 0; i < TN; i++)
 #pragma unroll
         for (int j = 0; j < TM; j++) {
-            const int m = m0 + wr * (BM / 2) + j * 16 + fr;
-            const int n = n0 + wc * (BN / 2) + i * 16 + fq * 4;
+            const int m = m0 + wr * (BM / WM) + j * 16 + fr;
+            const int n = n0 + wc * (BN / WN) + i * 16 + fq * 4;
             if (m < M) epi(m, n, acc[i][j]);
         }
 }
 
-template <int BM, int BN, class Epi>
+// 256 x 256 x 64 tile, 8 waves as 2 (m) x 4 (n), each owning 128 x 64 of the output, two 64 KB LDS stages.
+// The two waves that share a SIMD (waves w and w+4, i.e. the two row groups) run the same program
+// ONE BARRIER APART: a K-step is four barrier-delimited slots {read k-half 0, multiply it, read
+// k-half 1, multiply it}, so while one row group issues its 32 MFMAs the other one is reading its
+// fragments from LDS, and the matrix pipe of every SIMD always has exactly one wave feeding it.
+// Group 1 executes one extra barrier before the loop and group 0 one after it, so both see the same
+// number of barriers. The next K-step's LDS-DMA is issued by both groups in the same slot (group 0 at
+// the top of its read slot, group 1 at the top of its multiply slot) and retired with vmcnt(0) in
+// front of the barrier that precedes the first read of that stage, three slots later.
+template <class Epi>
+__global__ __launch_bounds__(512) void gemm_nt_stag_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
+                                                           int M, int N, int K, int gm, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, A_BYTES = BM * 128, STAGE = (BM + BN) * 128, TM = 8, TN = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    int bm, bn;
+    tile_coords(blockIdx.x, (M + BM - 1) / BM, N / BN, gm, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int j = 0; j < TM; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    const f16 *a_src = A + (long)(m0 + wave * 8 + srow) * lda + ((sslot ^ srow) << 3);
+    const f16 *w_src = W + (long)(n0 + wave * 8 + srow) * ldw + ((sslot ^ srow) << 3);
+    auto stage = [&](int kt, int buf) {
+        char *base = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src + (long)i * 64 * lda + (long)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(base + i * 8192), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_src + (long)i * 64 * ldw + (long)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(base + A_BYTES + i * 8192), 16, 0, 0);
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    f16x8 fa[TM], fw[TN];
+    auto read_frags = [&](int buf, int ks) {
+        const char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < TM; j++) {
+            const int row = grp * 128 + j * 16 + fr;
+            fa[j] = *(const f16x8 *)(sa + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TN; i++) {
+            const int row = wc * 64 + i * 16 + fr;
+            fw[i] = *(const f16x8 *)(sb + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto multiply = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int j = 0; j < TM; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto slot_end = [&]() { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
+
+    const int nk = K / BK;
+    stage(0, 0);
+    wait_vmcnt<0>();
+    slot_end();
+    if (grp == 1) {
+        if (nk > 1) stage(1, 1);
+        slot_end();
+    }
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (grp == 0 && kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        read_frags(buf, 0);
+        slot_end();
+        multiply();
+        slot_end();
+        read_frags(buf, 1);
+        if (grp == 1) wait_vmcnt<0>();
+        slot_end();
+        if (grp == 1 && kt + 2 < nk) stage(kt + 2, buf);
+        multiply();
+        if (grp == 0) wait_vmcnt<0>();
+        slot_end();
+    }
+    if (grp == 0) slot_end();
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int j = 0; j < TM; j++) {
+            const int m = m0 + grp * 128 + j * 16 + fr;
+            const int n = n0 + wc * 64 + i * 16 + fq * 4;
+            if (m < M) epi(m, n, acc[i][j]);
+        }
+}
+
+template <class Epi>
+static bool launch_stag(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st) {
+    if (M <= 0) return true;
+    if (N % 256 != 0 || K % BK != 0) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (tile 256x256)\n", M, N, K); return false; }
+    const int nblk = ((M + 255) / 256) * (N / 256);
+    constexpr size_t lds = 2 * 512 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)gemm_nt_stag_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_stag_kernel<Epi>), dim3(nblk), dim3(512), lds, st, A, lda, W, ldw, M, N, K, g_tile_group_rows, epi);
+    return hipGetLastError() == hipSuccess;
+}
+
+template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
 static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st) {
     if (M <= 0) return true;
     if (N % BN != 0 || K % BK != 0) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (tile %dx%d)\n", M, N, K, BM, BN); return false; }
     const int nblk = ((M + BM - 1) / BM) * (N / BN);
-    const size_t lds = 2 * (BM + BN) * 128;
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<BM, BN, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipFuncSetAttribute((const void *)gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, Epi>), dim3(nblk), dim3(256), lds, st, A, lda, W, ldw, M, N, K, epi);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>), dim3(nblk), dim3(64 * WM * WN), lds, st, A, lda, W, ldw, M, N, K, g_tile_group_rows, epi);
     return hipGetLastError() == hipSuccess;
 }
 
-// Tile choice: big tiles when the grid still fills the chip, smaller ones for skinny problems.
+// Tile choice: 256x256 (8 waves, 2 stages, LDS-DMA issue spread over the MFMA groups) when N allows it
+// and the grid fills the chip, then
+// 256x128 (8 waves, 3 stages, one workgroup per CU) when that grid still fills the chip,
+// 64x64 (4 waves, 4 stages) for the skinny decoder-side problems. Activation buffers are allocated with
+// their row count rounded up to 256, so the row tiles may over-read.
 template <class Epi>
 static bool dispatch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st) {
-    const long big = (long)((M + 127) / 128) * (N / 128);
-    if (N % 128 == 0 && big >= 192) return launch<128, 128, Epi>(A, lda, W, ldw, M, N, K, epi, st);
-    if (M > 64) return launch<128, 64, Epi>(A, lda, W, ldw, M, N, K, epi, st);
-    return launch<64, 64, Epi>(A, lda, W, ldw, M, N, K, epi, st);
+    const long big = (long)((M + 255) / 256) * (N / 128);
+    if (N % 256 == 0 && big >= 192) return launch<256, 256, 2, 4, 2, Epi, 8>(A, lda, W, ldw, M, N, K, epi, st);
+    if (N % 128 == 0 && M >= 192 && big >= 128) return launch<256, 128, 4, 2, 3, Epi>(A, lda, W, ldw, M, N, K, epi, st);
+    return launch<64, 64, 2, 2, 4, Epi>(A, lda, W, ldw, M, N, K, epi, st);
+}
+
+// Tile-shape A/B harness (benchmark only): same kernel, explicit variant.
+bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, hipStream_t st) {
+    const EpiF16 e{out, ldc, nullptr, 0, 1.0f};
+    switch (variant) {
+        case 0: return launch<256, 128, 4, 2, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 1: return launch<256, 256, 2, 4, 2, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 2: return launch<128, 128, 2, 2, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 3: return launch<128, 128, 2, 2, 2, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 4: return launch<256, 128, 4, 2, 2, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 5: return launch<128, 256, 2, 4, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 6: return launch<64, 64, 2, 2, 4, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 7: return launch<128, 64, 2, 2, 4, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 8: return launch_stag<EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 9: return launch<256, 256, 2, 4, 2, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);    // LDS-DMA issue spread over the MFMA groups
+        case 10: return launch<256, 128, 4, 2, 3, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);
+        case 11: return launch<256, 256, 2, 4, 2, EpiF16, 1>(A, lda, W, ldw, M, N, K, e, st);   // no global loads in the loop
+        case 12: return launch<256, 256, 2, 4, 2, EpiF16, 3>(A, lda, W, ldw, M, N, K, e, st);   // no global loads, no LDS reads
+        case 13: return launch<256, 256, 2, 4, 2, EpiF16, 4>(A, lda, W, ldw, M, N, K, e, st);   // no MFMA
+    }
+    return false;
 }
 
 bool gemm_f16(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st) {

@@ -14,6 +14,9 @@ bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int T
 bool gemm_cross_kv(const f16 *enc, const f16 *W, int M, int d, int H, int T, int Tp, int n_layer, f16 *out, const float *bias, const int *slots, hipStream_t st);
 bool gemm_dec_qkv(const f16 *xn, const f16 *W, int M, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st);
 
+extern int g_tile_group_rows;
+bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, hipStream_t st);
+
 // ---- k_mel.hip : log-mel frontend -----------------------------------------------------------
 struct MelTables {           // device-resident constants of one model
     const float *filters;    // [n_mel][201] dense table from the model file
@@ -54,8 +57,10 @@ bool dec_self_attention(const f16 *q, const f16 *kc, const f16 *vc, const int *b
 bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, int M, int d, int H, int T, int Tp, int n_layer, int layer, f16 *att, hipStream_t st);
 // logits rules + log-softmax + argmax / top-k / probabilities for every logit row
 // (the masked logits are written back in place; nst_bitmap has one bit per token id)
+// any_extra: some row has topk > 0 or want_probs; workspace: sample_workspace_bytes(max rows) of device memory
+size_t sample_workspace_bytes(int max_rows);
 bool sample_rows(float *logits, long ld, int R, const SampleRow *srow, const VocabIds &vi, const unsigned *nst_bitmap,
-                 SampleOut *out, TopkOut *topk, int topk_stride, float *probs, hipStream_t st);
+                 SampleOut *out, TopkOut *topk, int topk_stride, float *probs, bool any_extra, void *workspace, hipStream_t st);
 // copy KV page contents in every layer (beam fork of a partially filled page): pairs of (src_page, dst_page)
 bool copy_pages(f16 *kpool, f16 *vpool, long layer_stride, int n_layer, const int2 *pairs, int n_pairs, int H, hipStream_t st);
 

@@ -1,0 +1,17 @@
+"""A/B of GEMM tile variants on the encoder's shapes (run on the GPU box)."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from handy_amd import whisper_rs as wr
+L = wr.load_library()
+L.wmi_bench_gemm.restype = C.c_int
+L.wmi_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
+names = {0: "256x128 8w 3st", 1: "256x256 8w 2st", 2: "128x128 4w 3st", 3: "128x128 4w 2st", 4: "256x128 8w 2st", 5: "128x256 8w 3st", 6: "64x64 4w 4st", 7: "128x64 4w 4st", 8: "256x256 staggered", 9: "256x256 spread-dma", 10: "256x128 3st spread", 11: "256x256 no-gload", 12: "256x256 mfma-only", 13: "256x256 no-mfma"}
+shapes = [(24000, 5120, 1280), (24000, 1280, 5120), (24000, 3840, 1280), (24000, 1280, 1280)]
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 9, 0, 10]
+for (M, N, K) in shapes:
+    for rnd in range(2):
+        for v in variants:
+            ms = C.c_float()
+            rc = L.wmi_bench_gemm(M, N, K, v, 10, C.byref(ms))
+            tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12 if rc == 0 and ms.value > 0 else 0
+            print(f"M={M} N={N} K={K} round {rnd} variant {v} ({names[v]:15s}) rc={rc} {ms.value*1e3:8.1f} us {tf:7.1f} TF/s", flush=True)

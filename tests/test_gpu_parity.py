@@ -19,7 +19,7 @@ def _f16(x):
     return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 192, 256), (64, 64, 64), (1, 128, 128), (300, 256, 1280), (5, 51968 // 4, 128)])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 256), (64, 64, 64), (1, 128, 128), (300, 256, 1280), (5, 51968 // 4, 128), (3000, 2048, 256), (2047, 1280, 1280)])
 def test_gemm_matches_numpy(wr, M, N, K):
     rng = np.random.default_rng(M * 7 + N)
     A = rng.standard_normal((M, K), dtype=np.float32)
