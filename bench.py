@@ -134,17 +134,14 @@ def main():
     ptrs = [pcm_dev.data_ptr() + i * n_samp * 4 for i in range(B)]
     ns = [n_samp] * B
 
+    from handy_amd.node import gather_token_records, pack_token_records
+
     def step():
         st.full_batch_device(fp, ptrs, ns)
-        toks = np.full((B, args.tokens + 2), -1, dtype=np.int32)
-        for u in range(B):
-            t = st.batch_tokens(u)
-            toks[u, :len(t)] = t
-        if world > 1:       # the only collective on the path: gather the per-utterance token records
-            tt = torch.from_numpy(toks).to(dev)
-            out = [torch.empty_like(tt) for _ in range(world)] if rank == 0 else None
-            dist.gather(tt, out, dst=0)
-        return toks
+        rec = pack_token_records(range(rank * B, (rank + 1) * B), [st.batch_tokens(u) for u in range(B)], args.tokens + 2)
+        if world > 1:       # the only collective on the path: gather the per-utterance token records on rank 0 (RCCL)
+            gather_token_records(rec, B, device=dev)
+        return rec[:, 2:]
 
     for _ in range(args.warmup):
         toks = step()

@@ -1,0 +1,47 @@
+"""Node-level data parallelism by utterance: one process (one independent engine) per GPU, no tensor
+parallelism; the only collective is the gather of per-utterance token records at the end of a pass.
+Handy has no multi-GPU path (one engine behind one mutex, reference
+src-tauri/src/managers/transcription.rs:39, :383); this module is what a bulk driver runs on top of the
+batch entry point."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+def shard_indices(n_total: int, rank: int, world: int) -> np.ndarray:
+    """Contiguous, balanced shard of utterance indices for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_total, world)
+    start = rank * base + min(rank, rem)
+    return np.arange(start, start + base + (1 if rank < rem else 0), dtype=np.int64)
+
+
+def pack_token_records(index: Sequence[int], tokens: Sequence[Sequence[int]], width: int) -> np.ndarray:
+    """Fixed-size records [utterance index, n_tokens, tokens..., -1 padding] so the gather is one dense tensor."""
+    rec = np.full((len(index), width + 2), -1, dtype=np.int32)
+    for i, (u, t) in enumerate(zip(index, tokens)):
+        t = list(t)[:width]
+        rec[i, 0], rec[i, 1] = u, len(t)
+        rec[i, 2:2 + len(t)] = t
+    return rec
+
+
+def gather_token_records(rec: np.ndarray, rows_per_rank: int, device=None) -> Optional[np.ndarray]:
+    """Gathers every rank's records on rank 0 (RCCL when the default group is 'nccl', gloo on CPU).
+    Ranks pad to `rows_per_rank` rows; rank 0 returns the records sorted by utterance index, others None."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    pad = np.full((rows_per_rank, rec.shape[1]), -1, dtype=np.int32)
+    pad[:len(rec)] = rec
+    t = torch.from_numpy(pad)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, out, dst=0)
+    if rank != 0:
+        return None
+    allr = torch.cat(out).cpu().numpy()
+    allr = allr[allr[:, 0] >= 0]
+    return allr[np.argsort(allr[:, 0], kind="stable")]

@@ -1,0 +1,131 @@
+"""CPU suite, part 2: host-side logic and the C-ABI boundary (the library must load and export every
+declared symbol without a GPU; no compute entry point is called here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_in_headers():
+    names = []
+    for h in ("whisper.h", "wmi.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        names += [n for n in re.findall(r"^WHISPER_API[^;(]*?\b(\w+)\s*\(", src, flags=re.M) if n != "__attribute__"]
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from handy_amd import whisper_rs as wr
+    assert os.path.exists(wr.LIB_PATH), "build the extension first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = C.CDLL(wr.LIB_PATH)
+    declared = _declared_in_headers()
+    assert len(declared) > 100
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(set(declared)) == sorted(set(wr.DECLARED_SYMBOLS) | {"wmi_bench_gemm", "wmi_debug_set_tile_group"})
+    out = subprocess.run(["nm", "-D", "--defined-only", wr.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ggml_" not in out          # Handy isolates llama.cpp in a sidecar because of ggml symbol clashes (local_llm.rs:1-4)
+
+
+def test_struct_layout_matches_the_c_header(tmp_path):
+    """The ctypes mirror of the by-value structs must have the layout the C compiler gives whisper.h."""
+    from handy_amd import whisper_rs as wr
+    src = tmp_path / "layout.c"
+    fields = ["strategy", "translate", "token_timestamps", "max_tokens", "audio_ctx", "tdrz_enable", "suppress_regex", "prompt_n_tokens",
+              "language", "detect_language", "suppress_blank", "suppress_nst", "temperature", "no_speech_thold", "greedy", "beam_search",
+              "new_segment_callback", "grammar_rules", "grammar_penalty"]
+    body = "".join(f'printf("{f} %zu\\n", offsetof(struct whisper_full_params, {f}));\n' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "whisper.h"\nint main(void){\n'
+                   'printf("full %zu\\nctx %zu\\ntok %zu\\n", sizeof(struct whisper_full_params), sizeof(struct whisper_context_params), sizeof(whisper_token_data));\n'
+                   + body + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(out["full"]) == C.sizeof(wr.whisper_full_params)
+    assert int(out["ctx"]) == C.sizeof(wr.whisper_context_params)
+    assert int(out["tok"]) == C.sizeof(wr.whisper_token_data)
+    for f in fields:
+        assert int(out[f]) == getattr(wr.whisper_full_params, f).offset, f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from handy_amd import whisper_rs as wr
+    with pytest.raises(wr.WhisperError):
+        wr.load_library(str(tmp_path / "libnothing.so"))
+
+
+def test_ggml_writer_reader_roundtrip(tmp_path):
+    from handy_amd import ggml_file as gf
+    p = str(tmp_path / "m.bin")
+    hp = gf.write_synthetic_model(p, "micro", seed=3)
+    m = gf.read_model(p)
+    assert m.hp.as_list() == hp.as_list() and m.filters.shape == (80, 201) and len(m.vocab) == 50257
+    assert m.vocab[220] == b" "
+    names = [n for n, _ in gf.tensor_specs(hp)]
+    assert list(m.tensors) == names
+    assert m.tensors["encoder.conv1.bias"].shape == (128, 1) and m.ttypes["encoder.blocks.1.mlp.0.weight"] == gf.T_F16
+    again = str(tmp_path / "m2.bin")
+    gf.write_synthetic_model(again, "micro", seed=3)
+    assert open(p, "rb").read() == open(again, "rb").read()                 # seeded => byte-identical
+    f = gf.mel_filterbank(80)
+    assert f.shape == (80, 201) and np.all(f >= 0) and np.all((f > 0).sum(axis=1) >= 1) and abs(float(f[10].sum()) - 0.0249) < 5e-3
+    assert gf.sinusoids(1500, 128).shape == (1500, 128)
+
+
+def test_synth_audio_is_deterministic_and_bounded():
+    from handy_amd.synth import synth_batch, synth_pcm
+    a, b = synth_pcm(5), synth_pcm(5)
+    assert a.dtype == np.float32 and a.shape == (480000,) and np.array_equal(a, b)
+    assert np.abs(a).max() <= 1.0 and a.std() > 0.01 and not np.array_equal(a, synth_pcm(6))
+    assert synth_batch(0, 3, 1600).shape == (3, 1600)
+
+
+def test_sharding_and_record_packing():
+    from handy_amd.node import pack_token_records, shard_indices
+    for n, w in ((10000, 8), (7, 4), (3, 8), (0, 2)):
+        shards = [shard_indices(n, r, w) for r in range(w)]
+        assert np.array_equal(np.concatenate(shards), np.arange(n))
+        assert max(map(len, shards)) - min(map(len, shards)) <= 1
+    rec = pack_token_records([4, 9], [[1, 2, 3], list(range(300))], 226)
+    assert rec.shape == (2, 228) and rec[0, :5].tolist() == [4, 3, 1, 2, 3] and rec[0, 5] == -1 and rec[1, 1] == 226
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+from handy_amd.node import shard_indices, pack_token_records, gather_token_records
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+rank, n = dist.get_rank(), 11
+idx = shard_indices(n, rank, 2)
+toks = [[int(u) * 10 + k for k in range(int(u) % 4)] for u in idx]          # ragged, empty ones included
+rec = pack_token_records(idx, toks, 8)
+out = gather_token_records(rec, rows_per_rank=6)
+if rank == 0:
+    assert out[:, 0].tolist() == list(range(n)), out[:, 0]
+    for u in range(n):
+        assert out[u, 1] == u % 4 and out[u, 2:2 + u % 4].tolist() == [u * 10 + k for k in range(u % 4)]
+    print("GATHER_OK")
+else:
+    assert out is None
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_process_gather_over_gloo(tmp_path):
+    """The N>1 path (shard by utterance, gather token records on rank 0) with world_size 2 on CPU."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]
