@@ -392,6 +392,7 @@ int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C
     WMI_CATCH(-1)
 }
 
+int wmi_debug_read_gemm_stamps(unsigned long long *out, int n) { return wmi::gemm_read_stamps(out, n) ? 0 : -1; }
 void wmi_debug_set_tile_group(int rows) { if (rows >= 1) wmi::g_tile_group_rows = rows; }
 
 // GEMM tile-shape harness: random fp16 operands, `iters` launches of one variant, average ms by HIP events.
@@ -420,6 +421,38 @@ int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(da); (void)hipFree(dw); (void)hipFree(dc);
+    return rc;
+    WMI_CATCH(-1)
+}
+
+// Harness: the same random operands through two tile variants; returns the largest |difference| of the fp16 outputs.
+int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_variant, float *max_abs_diff) {
+    WMI_TRY
+    if (M <= 0 || N % 256 || K % 64 || !max_abs_diff) return -1;
+    const size_t Mp = round_up(M, 256);
+    std::vector<f16> a(Mp * K), w((size_t)N * K), c0((size_t)M * N), c1((size_t)M * N);
+    uint32_t x = 777u;
+    auto rnd = [&]() { x = x * 1664525u + 1013904223u; return (float)((int)(x >> 9) % 2001 - 1000) * 1e-3f; };
+    for (auto &v : a) v = (f16)rnd();
+    for (auto &v : w) v = (f16)rnd();
+    f16 *da = nullptr, *dw = nullptr, *dc = nullptr;
+    int rc = -1;
+    if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess && hipMalloc(&dc, Mp * N * 2 + 4096) == hipSuccess &&
+        hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemset(dc, 0xff, Mp * N * 2) == hipSuccess &&
+        gemm_variant(variant, da, K, dw, K, M, N, K, dc, N, nullptr) && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(c0.data(), dc, c0.size() * 2, hipMemcpyDeviceToHost) == hipSuccess && hipMemset(dc, 0xff, Mp * N * 2) == hipSuccess &&
+        gemm_variant(ref_variant, da, K, dw, K, M, N, K, dc, N, nullptr) && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(c1.data(), dc, c1.size() * 2, hipMemcpyDeviceToHost) == hipSuccess) {
+        float d = 0;
+        for (size_t i = 0; i < c0.size(); i++) {
+            const float e = fabsf((float)c0[i] - (float)c1[i]);
+            d = (e == e) ? fmaxf(d, e) : INFINITY;
+        }
+        *max_abs_diff = d;
+        rc = 0;
+    }
     (void)hipFree(da); (void)hipFree(dw); (void)hipFree(dc);
     return rc;
     WMI_CATCH(-1)

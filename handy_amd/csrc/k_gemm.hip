@@ -36,18 +36,26 @@ __device__ __forceinline__ float gelu_f16_dev(float x) {
 // ------------------------------------------------------------------------------------------ epilogues
 // Each epilogue receives one lane's 4 accumulators: row m, columns n..n+3 (n % 4 == 0).
 
+// An epilogue whose output is f16 and contiguous along n also offers value() (the 4 results of one
+// lane, not stored) and store8() (8 consecutive columns of one row, n % 8 == 0): the big-tile kernel
+// then pairs lanes so that every store instruction moves 16 bytes per lane.
+
 struct EpiF16 {            // out[m][n] = f16(act((acc + bias) * scale))
+    static constexpr bool kWide = true;
     f16 *out; long ldc; const float *bias; int gelu; float scale;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
+    __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         if (bias) { const f32x4 b = *(const f32x4 *)(bias + n); a += b; }
         a *= scale;
         if (gelu) { a[0] = gelu_f16_dev(a[0]); a[1] = gelu_f16_dev(a[1]); a[2] = gelu_f16_dev(a[2]); a[3] = gelu_f16_dev(a[3]); }
-        f16x4 h = {(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
-        *(f16x4 *)(out + (long)m * ldc + n) = h;
+        return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
+    __device__ __forceinline__ bool wide(int n) const { return true; }
+    __device__ __forceinline__ void store8(int m, int n, f16x8 h) const { *(f16x8 *)(out + (long)m * ldc + n) = h; }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { *(f16x4 *)(out + (long)m * ldc + n) = value(m, n, a); }
 };
 
 struct EpiF32 {            // out[m][n] = acc + bias
+    static constexpr bool kWide = false;
     float *out; long ldc; const float *bias;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
         if (bias) { const f32x4 b = *(const f32x4 *)(bias + n); a += b; }
@@ -56,6 +64,7 @@ struct EpiF32 {            // out[m][n] = acc + bias
 };
 
 struct EpiResidual {       // x[m][n] += acc + bias   (fp32 residual stream, in place)
+    static constexpr bool kWide = false;
     float *x; long ldc; const float *bias;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
         float *p = x + (long)m * ldc + n;
@@ -66,19 +75,24 @@ struct EpiResidual {       // x[m][n] += acc + bias   (fp32 residual stream, in 
 };
 
 struct EpiConv1 {          // rows have period P = 2T+2 per utterance; h1[m+1][n] = t < 2T ? gelu(acc+b) : 0
+    static constexpr bool kWide = true;
     f16 *h1; int d; const float *bias; int period; int t_valid;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
+    __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         const int t = m % period;
         f16x4 h = {(f16)0, (f16)0, (f16)0, (f16)0};
         if (t < t_valid) {
             const f32x4 b = *(const f32x4 *)(bias + n); a += b;
             h = f16x4{(f16)gelu_f16_dev(a[0]), (f16)gelu_f16_dev(a[1]), (f16)gelu_f16_dev(a[2]), (f16)gelu_f16_dev(a[3])};
         }
-        *(f16x4 *)(h1 + (long)(m + 1) * d + n) = h;
+        return h;
     }
+    __device__ __forceinline__ bool wide(int n) const { return true; }
+    __device__ __forceinline__ void store8(int m, int n, f16x8 h) const { *(f16x8 *)(h1 + (long)(m + 1) * d + n) = h; }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { *(f16x4 *)(h1 + (long)(m + 1) * d + n) = value(m, n, a); }
 };
 
 struct EpiConv2 {          // rows have period T+1; x[b*T+t][n] = gelu(acc+b) + pos_emb[t][n], junk row t==T dropped
+    static constexpr bool kWide = false;
     float *x; int d; const float *bias; const float *pe; int T;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
         const int b = m / (T + 1), t = m - b * (T + 1);
@@ -91,7 +105,19 @@ struct EpiConv2 {          // rows have period T+1; x[b*T+t][n] = gelu(acc+b) + 
 };
 
 struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -> K[b][h][t][64]; [2d,3d): V -> Vt[b][h][64][Tp]
+    static constexpr bool kWide = true;
     f16 *Q, *K, *Vt; const float *bias; int d, H, T, Tp;
+    __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
+        const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
+        if (n < d) a *= 0.125f;
+        return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+    }
+    __device__ __forceinline__ bool wide(int n) const { return n < 2 * d; }      // the V part is stored transposed, element by element
+    __device__ __forceinline__ void store8(int m, int n, f16x8 o) const {
+        const int b = m / T, t = m - b * T;
+        const int part = n >= d, c = n - part * d, h = c >> 6, e = c & 63;
+        *(f16x8 *)((part ? K : Q) + (((long)b * H + h) * Tp + t) * 64 + e) = o;
+    }
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
         const int b = m / T, t = m - b * T;
         const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
@@ -110,18 +136,25 @@ struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -
 };
 
 struct EpiCrossKV {        // n = (layer*2 + kv)*d + h*64 + e ; out[slot(b)][layer][kv][h][t][64]
+    static constexpr bool kWide = true;
     f16 *out; const float *bias; const int *slots; int d, H, T, Tp, n_layer;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
+    __device__ __forceinline__ f16 *dest(int m, int n) const {
         const int b = m / T, t = m - b * T;
-        const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
         const int lk = n / d, c = n - lk * d, h = c >> 6, e = c & 63;
         const long slot = slots[b];
-        f16x4 o = {(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
-        *(f16x4 *)(out + ((((slot * n_layer * 2 + lk) * H + h) * (long)Tp) + t) * 64 + e) = o;
+        return out + ((((slot * n_layer * 2 + lk) * H + h) * (long)Tp) + t) * 64 + e;
     }
+    __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
+        const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
+        return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+    }
+    __device__ __forceinline__ bool wide(int n) const { return true; }
+    __device__ __forceinline__ void store8(int m, int n, f16x8 o) const { *(f16x8 *)dest(m, n) = o; }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { *(f16x4 *)dest(m, n) = value(m, n, a); }
 };
 
 struct EpiDecQKV {         // q -> qbuf[m][d] * 1/8 ; k,v -> paged cache [page][H][16][64] at rows[m].kv_index
+    static constexpr bool kWide = false;
     f16 *q, *kc, *vc; const float *bias; const DecRow *rows; int d, H;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
         const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
@@ -143,6 +176,7 @@ struct EpiDecQKV {         // q -> qbuf[m][d] * 1/8 ; k,v -> paged cache [page][
 // gets a contiguous run of logical ids, and logical ids walk the tile grid in groups of 8 tile rows x
 // all tile columns, column-major inside a group, so the ~32 tiles an XCD works on at one time form an
 // 8 x 4 patch that shares 8 activation panels and 4 weight panels through that L2.
+__device__ unsigned long long g_gemm_stamps[2048 * 8 * 8];      // diagnostic builds of the harness only (see gemm_variant)
 int g_tile_group_rows = 8;     // tile rows per group (harness knob; 8 is the shipped value)
 
 __device__ __forceinline__ void tile_coords(int p, int nbm, int nbn, int GM, int &bm, int &bn) {
@@ -154,12 +188,64 @@ __device__ __forceinline__ void tile_coords(int p, int nbm, int nbn, int GM, int
     bm = first + (w - bn * rows);
 }
 
+// Output of one wave's TM x TN grid of 16x16 accumulator tiles. A lane holds row (lane & 15), columns
+// 4*(lane >> 4)..+3 of each tile. For f16 row-major destinations two vertically adjacent tiles X, Y are
+// exchanged between lane pairs with v_permlane16_swap (odd 16-lane rows of one register <-> even rows of
+// the other): afterwards a lane holds 8 consecutive columns (8*(lane >> 5)..+7) of one row of X (even
+// 16-lane row) or Y (odd row) and stores them as one 16-byte vector -- half the store instructions, and the
+// store tail of a tile is bound by their issue rate.
+template <int TM, int TN, class Epi>
+__device__ __forceinline__ void write_tile(const Epi &epi, f32x4 (&acc)[TN][TM], int M, int mw, int nw, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (Epi::kWide && TM % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < TN; i++) {
+            const int n = nw + i * 16;
+            if (epi.wide(n)) {
+#pragma unroll
+                for (int j = 0; j < TM; j += 2) {
+                    const int mx = mw + j * 16 + fr, my = mx + 16;
+                    union { f16x4 h; unsigned u[2]; } x, y;
+                    x.h = epi.value(mx, n + fq * 4, acc[i][j]);
+                    y.h = epi.value(my, n + fq * 4, acc[i][j + 1]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(x.u[0], y.u[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(x.u[1], y.u[1], false, false);
+                    union { f16x8 h; unsigned u[4]; } o;
+                    o.u[0] = s0[0]; o.u[1] = s1[0]; o.u[2] = s0[1]; o.u[3] = s1[1];
+                    const int m = (fq & 1) ? my : mx;
+                    if (m < M) epi.store8(m, n + (fq >> 1) * 8, o.h);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TM; j++) {
+                    const int m = mw + j * 16 + fr;
+                    if (m < M) epi(m, n + fq * 4, acc[i][j]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int j = 0; j < TM; j++) {
+                const int m = mw + j * 16 + fr;
+                if (m < M) epi(m, nw + i * 16 + fq * 4, acc[i][j]);
+            }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BM x BN output tile, WM x WN waves (each owns a (BM/WM) x (BN/WN) sub-tile), NST LDS stages.
 // Stage s+NST-1 is issued while stage s is multiplied, so NST-2 whole stages stay in flight across
 // each barrier: the wait before the barrier is a COUNTED vmcnt (never 0 in the steady state) and the
 // barrier is the raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
+// MODE bits. Schedule (shipped on the 256x256 tile): kSpread issues the next stage's LDS-DMA between the MFMA
+// groups instead of in one burst after the barrier; kFirstHalf confines that to the first k-half of the step,
+// so the loads get the second half's MFMAs as extra time to land. Harness-only builds: kNoLoads / kNoLdsReads /
+// kNoMfma drop one ingredient of the loop (ablation timing), kStamps records s_memtime per loop section.
+enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32 };
+
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
                                                                 int M, int N, int K, int gm, Epi epi) {
@@ -212,15 +298,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
         if (s < nk) stage(s, s);
     const int fr = lane & 15, fq = lane >> 4;
     int buf = 0, nbuf = NST - 1;       // buffer being multiplied / buffer the next stage goes to
+    unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, t_prev = 0, t_start = 0, t_pro = 0;
+    if (ABL & 16) t_start = t_prev = __builtin_amdgcn_s_memtime();
     for (int kt = 0; kt < nk; kt++) {
         // stage kt has landed once at most min(NST-2, nk-1-kt) younger stages are still outstanding
         const int younger = nk - 1 - kt;
         if (NST >= 4 && younger >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LPS>();
         else if (NST >= 3 && younger >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LPS>();
         else wait_vmcnt<0>();
+        if ((ABL & 16) && kt > 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - t_prev; t_prev = t; }
         __builtin_amdgcn_s_barrier();
+        if (ABL & 16) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (kt > 0) t_bar += t - t_prev; else t_pro = t - t_prev; t_prev = t; }
         const bool more = kt + NST - 1 < nk;
-        if ((ABL & 1) == 0 && (ABL & 8) == 0 && more) stage(kt + NST - 1, nbuf);      // ABL bits: ablation builds of the harness only
+        if ((ABL & kNoLoads) == 0 && (ABL & kSpread) == 0 && more) stage(kt + NST - 1, nbuf);
         const char *sa = smem + ((ABL & 1) ? 0 : buf) * STAGE, *sb = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -245,11 +335,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
             } else {
 #pragma unroll
                 for (int i = 0; i < TN; i++) {
-                    if ((ABL & 8) && more) {          // spread the LDS-DMA issue over the MFMA groups
-                        constexpr int per = (LPS + 2 * TN - 1) / (2 * TN);
+                    if ((ABL & 8) && more && (!(ABL & 32) || ks == 0)) {          // spread the LDS-DMA issue over the MFMA groups
+                        constexpr int per = (ABL & 32) ? (LPS + TN - 1) / TN : (LPS + 2 * TN - 1) / (2 * TN);
 #pragma unroll
                         for (int u = 0; u < per; u++) {
-                            const int li = (ks * TN + i) * per + u;
+                            const int li = ((ABL & 32) ? i : ks * TN + i) * per + u;
                             if (li < LA) stage_piece(kt + NST - 1, nbuf, li, true);
                             else if (li < LPS) stage_piece(kt + NST - 1, nbuf, li - LA, false);
                         }
@@ -263,133 +353,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
         }
         buf = buf + 1 == NST ? 0 : buf + 1;
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+        if (ABL & 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); t_comp += t - t_prev; t_prev = t; }
     }
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++) {
-            const int m = m0 + wr * (BM / WM) + j * 16 + fr;
-            const int n = n0 + wc * (BN / WN) + i * 16 + fq * 4;
-            if (m < M) epi(m, n, acc[i][j]);
+    write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
+    if ((ABL & 16) && blockIdx.x < 2048) {
+        const unsigned long long t_issue = __builtin_amdgcn_s_memtime();
+        wait_vmcnt<0>();
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long *o = g_gemm_stamps + ((long)blockIdx.x * 8 + (wave & 7)) * 8;
+            o[0] = t_wait; o[1] = t_bar; o[2] = t_comp; o[3] = nk; o[4] = t_start; o[5] = t_pro; o[6] = t_issue - t_prev; o[7] = t_end;
         }
-}
-
-// 256 x 256 x 64 tile, 8 waves as 2 (m) x 4 (n), each owning 128 x 64 of the output, two 64 KB LDS stages.
-// The two waves that share a SIMD (waves w and w+4, i.e. the two row groups) run the same program
-// ONE BARRIER APART: a K-step is four barrier-delimited slots {read k-half 0, multiply it, read
-// k-half 1, multiply it}, so while one row group issues its 32 MFMAs the other one is reading its
-// fragments from LDS, and the matrix pipe of every SIMD always has exactly one wave feeding it.
-// Group 1 executes one extra barrier before the loop and group 0 one after it, so both see the same
-// number of barriers. The next K-step's LDS-DMA is issued by both groups in the same slot (group 0 at
-// the top of its read slot, group 1 at the top of its multiply slot) and retired with vmcnt(0) in
-// front of the barrier that precedes the first read of that stage, three slots later.
-template <class Epi>
-__global__ __launch_bounds__(512) void gemm_nt_stag_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
-                                                           int M, int N, int K, int gm, Epi epi) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 256, BN = 256, A_BYTES = BM * 128, STAGE = (BM + BN) * 128, TM = 8, TN = 4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wc = wave & 3;
-    int bm, bn;
-    tile_coords(blockIdx.x, (M + BM - 1) / BM, N / BN, gm, bm, bn);
-    const int m0 = bm * BM, n0 = bn * BN;
-
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++) acc[i][j] = f32x4{0, 0, 0, 0};
-
-    const int srow = lane >> 3, sslot = lane & 7;
-    const f16 *a_src = A + (long)(m0 + wave * 8 + srow) * lda + ((sslot ^ srow) << 3);
-    const f16 *w_src = W + (long)(n0 + wave * 8 + srow) * ldw + ((sslot ^ srow) << 3);
-    auto stage = [&](int kt, int buf) {
-        char *base = smem + buf * STAGE + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src + (long)i * 64 * lda + (long)kt * BK),
-                                             (__attribute__((address_space(3))) void *)(base + i * 8192), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_src + (long)i * 64 * ldw + (long)kt * BK),
-                                             (__attribute__((address_space(3))) void *)(base + A_BYTES + i * 8192), 16, 0, 0);
-    };
-    const int fr = lane & 15, fq = lane >> 4;
-    f16x8 fa[TM], fw[TN];
-    auto read_frags = [&](int buf, int ks) {
-        const char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < TM; j++) {
-            const int row = grp * 128 + j * 16 + fr;
-            fa[j] = *(const f16x8 *)(sa + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < TN; i++) {
-            const int row = wc * 64 + i * 16 + fr;
-            fw[i] = *(const f16x8 *)(sb + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto multiply = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < TN; i++)
-#pragma unroll
-            for (int j = 0; j < TM; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto slot_end = [&]() { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
-
-    const int nk = K / BK;
-    stage(0, 0);
-    wait_vmcnt<0>();
-    slot_end();
-    if (grp == 1) {
-        if (nk > 1) stage(1, 1);
-        slot_end();
     }
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
-        if (grp == 0 && kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        read_frags(buf, 0);
-        slot_end();
-        multiply();
-        slot_end();
-        read_frags(buf, 1);
-        if (grp == 1) wait_vmcnt<0>();
-        slot_end();
-        if (grp == 1 && kt + 2 < nk) stage(kt + 2, buf);
-        multiply();
-        if (grp == 0) wait_vmcnt<0>();
-        slot_end();
-    }
-    if (grp == 0) slot_end();
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++) {
-            const int m = m0 + grp * 128 + j * 16 + fr;
-            const int n = n0 + wc * 64 + i * 16 + fq * 4;
-            if (m < M) epi(m, n, acc[i][j]);
-        }
-}
-
-template <class Epi>
-static bool launch_stag(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st) {
-    if (M <= 0) return true;
-    if (N % 256 != 0 || K % BK != 0) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (tile 256x256)\n", M, N, K); return false; }
-    const int nblk = ((M + 255) / 256) * (N / 256);
-    constexpr size_t lds = 2 * 512 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)gemm_nt_stag_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_nt_stag_kernel<Epi>), dim3(nblk), dim3(512), lds, st, A, lda, W, ldw, M, N, K, g_tile_group_rows, epi);
-    return hipGetLastError() == hipSuccess;
 }
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
@@ -415,7 +390,7 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
 template <class Epi>
 static bool dispatch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st) {
     const long big = (long)((M + 255) / 256) * (N / 128);
-    if (N % 256 == 0 && big >= 192) return launch<256, 256, 2, 4, 2, Epi, 8>(A, lda, W, ldw, M, N, K, epi, st);
+    if (N % 256 == 0 && big >= 192) return launch<256, 256, 2, 4, 2, Epi, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 128 == 0 && M >= 192 && big >= 128) return launch<256, 128, 4, 2, 3, Epi>(A, lda, W, ldw, M, N, K, epi, st);
     return launch<64, 64, 2, 2, 4, Epi>(A, lda, W, ldw, M, N, K, epi, st);
 }
@@ -432,14 +407,19 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 5: return launch<128, 256, 2, 4, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 6: return launch<64, 64, 2, 2, 4, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 7: return launch<128, 64, 2, 2, 4, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
-        case 8: return launch_stag<EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 9: return launch<256, 256, 2, 4, 2, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);    // LDS-DMA issue spread over the MFMA groups
         case 10: return launch<256, 128, 4, 2, 3, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);
+        case 15: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 32>(A, lda, W, ldw, M, N, K, e, st);
+        case 14: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16>(A, lda, W, ldw, M, N, K, e, st);   // with per-section cycle stamps
         case 11: return launch<256, 256, 2, 4, 2, EpiF16, 1>(A, lda, W, ldw, M, N, K, e, st);   // no global loads in the loop
         case 12: return launch<256, 256, 2, 4, 2, EpiF16, 3>(A, lda, W, ldw, M, N, K, e, st);   // no global loads, no LDS reads
         case 13: return launch<256, 256, 2, 4, 2, EpiF16, 4>(A, lda, W, ldw, M, N, K, e, st);   // no MFMA
     }
     return false;
+}
+
+bool gemm_read_stamps(unsigned long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * n) == hipSuccess;
 }
 
 bool gemm_f16(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st) {

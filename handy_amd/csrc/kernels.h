@@ -15,6 +15,7 @@ bool gemm_cross_kv(const f16 *enc, const f16 *W, int M, int d, int H, int T, int
 bool gemm_dec_qkv(const f16 *xn, const f16 *W, int M, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st);
 
 extern int g_tile_group_rows;
+bool gemm_read_stamps(unsigned long long *out, int n);
 bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, hipStream_t st);
 
 // ---- k_mel.hip : log-mel frontend -----------------------------------------------------------

@@ -59,7 +59,9 @@ WHISPER_API int wmi_get_cross_kv(struct whisper_state *state, int layer, float *
 WHISPER_API int wmi_decode_logits_all(struct whisper_context *ctx, struct whisper_state *state, const whisper_token *tokens, int n_tokens, int n_past, float *logits_out);
 WHISPER_API int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C);          /* C = f16(A) f16(W)^T on the device */
 
+WHISPER_API int wmi_debug_read_gemm_stamps(unsigned long long *out, int n);                             /* harness: per-section cycle sums of variant 14 */
 WHISPER_API void wmi_debug_set_tile_group(int rows);                                                    /* harness knob: tile rows per L2 group */
+WHISPER_API int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_variant, float *max_abs_diff); /* harness */
 WHISPER_API int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out);            /* tile-shape A/B harness, random fp16 operands */
 
 /* Per-kernel-class device time, measured with HIP events on the engine's stream. */
