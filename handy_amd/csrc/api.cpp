@@ -364,7 +364,8 @@ int wmi_get_cross_kv(struct whisper_state *s, int layer, float *k, float *v) {
     Engine *e = ENG(s); return e && k && v ? e->get_cross_kv(layer, k, v) : -1;
     WMI_CATCH(-1)
 }
-void wmi_set_profiling(struct whisper_state *s, int on) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = on != 0; } }
+void wmi_set_profiling(struct whisper_state *s, int on) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = on != 0; e->profile_mask = ~0u; } }
+void wmi_set_profiling_classes(struct whisper_state *s, unsigned class_mask) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = class_mask != 0; e->profile_mask = class_mask; } }
 int wmi_get_kernel_stats(struct whisper_state *s, wmi_kernel_stat *out) {
     Engine *e = ENG(s); if (!e || !out) return -1;
     try { e->collect_stats(); } catch (...) { return -1; }
@@ -408,7 +409,8 @@ int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {
     f16 *da = nullptr, *dw = nullptr, *dc = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = -1;
-    if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess && hipMalloc(&dc, Mp * N * 2 + 4096) == hipSuccess &&
+    if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess &&
+        hipMalloc(&dc, std::max(Mp * N * 2 + 4096, wmi::gemm_splitk_workspace_bytes())) == hipSuccess &&      // variant 30 writes split-K partials here
         hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
         hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         bool ok = true;

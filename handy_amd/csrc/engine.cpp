@@ -102,6 +102,7 @@ bool Engine::alloc_workspaces() {
     ok &= out_dev_.ensure((size_t)lrows_cap_ * (sizeof(SampleOut) + 8 * sizeof(TopkOut)));
     ok &= out_host_.ensure((size_t)lrows_cap_ * (sizeof(SampleOut) + 8 * sizeof(TopkOut)));
     ok &= sample_ws_.ensure(sample_workspace_bytes(lrows_cap_));
+    ok &= splitk_ws_.ensure(gemm_splitk_workspace_bytes());
     logits_host_.assign(V_, 0.0f);
     ok &= ensure_rows(std::max(128, max_seqs));
     return ok;
@@ -120,7 +121,7 @@ bool Engine::ensure_rows(int rows) {
 
 // ------------------------------------------------------------------------------------------ profiling
 void Engine::prof_begin(int cls, double work) {
-    if (!profiling) return;
+    if (!profiling || !((profile_mask >> cls) & 1u)) return;
     if (ev_used_ == ev_pool_.size()) {
         EvPair e{};
         if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -358,23 +359,60 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     if (C) PROF(WMI_K_DEC_OTHER, 0, copy_pages(kp, vp, layer_stride_, Ld_, d_copy, C, H_, stream_));
     PROF(WMI_K_DEC_OTHER, (double)R * d * 6, dec_embed(model->d_te, model->d_pe, d_rows, R, d, dx_.as<float>(), stream_));
     const double ln_bytes = (double)R * d * 6, w1 = 2.0 * d * d;           // bytes of one d x d fp16 weight
+    // Skinny GEMMs go through split-K (partials in splitk_ws_, summed by the consumer that also applies the
+    // epilogue and, for the residual GEMMs, the LayerNorm that follows); wide passes use the fused epilogues.
+    float *ws = splitk_ws_.as<float>();
+    const int s_qkv = gemm_pick_splits(R, 3 * d, d), s_dd = gemm_pick_splits(R, d, d), s_fc1 = gemm_pick_splits(R, 4 * d, d), s_fc2 = gemm_pick_splits(R, d, 4 * d);
+    const bool fused_ln = s_dd > 1 && s_fc2 > 1;      // x += ... and the next LayerNorm in one kernel
+    auto residual_ln = [&](const f16 *a, int K, const f16 *Wt, const float *bias, int splits, const float *lw, const float *lb, f16 *out, const int *gather, int n_out) -> bool {
+        PROF(WMI_K_DEC_GEMM, 2.0 * d * K, gemm_splitk(a, K, Wt, K, R, d, K, splits, ws, stream_));
+        PROF(WMI_K_DEC_OTHER, ln_bytes, splitk_residual_ln(dx_.as<float>(), ws, splits, bias, lw, lb, out, R, d, gather, n_out, stream_));
+        return true;
+    };
+    if (fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), model->dec[0].ln1_w, model->dec[0].ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
     for (int l = 0; l < Ld_; l++) {
         const DecLayer &D = model->dec[l];
         f16 *kl = kp + l * layer_stride_, *vl = vp + l * layer_stride_;
-        PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln1_w, D.ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
-        PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_dec_qkv(dxn_.as<f16>(), D.wqkv, R, d, H_, dq_.as<f16>(), kl, vl, D.bqkv, d_rows, stream_));
+        if (!fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln1_w, D.ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
+        if (s_qkv > 1) {
+            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_splitk(dxn_.as<f16>(), d, D.wqkv, d, R, 3 * d, d, s_qkv, ws, stream_));
+            PROF(WMI_K_DEC_OTHER, (double)R * 3 * d * 2, splitk_dec_qkv(ws, s_qkv, D.bqkv, d_rows, R, d, H_, dq_.as<f16>(), kl, vl, stream_));
+        } else {
+            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_dec_qkv(dxn_.as<f16>(), D.wqkv, R, d, H_, dq_.as<f16>(), kl, vl, D.bqkv, d_rows, stream_));
+        }
         PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(dq_.as<f16>(), kl, vl, d_bt, d_rows, R, d, H_, datt_.as<f16>(), stream_));
-        PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.wo, d, R, d, d, dx_.as<float>(), d, D.bo, stream_));
-        PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.lnx_w, D.lnx_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
-        PROF(WMI_K_DEC_GEMM, w1, gemm_f16(dxn_.as<f16>(), d, D.xq, d, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_));
+        if (fused_ln) { if (!residual_ln(datt_.as<f16>(), d, D.wo, D.bo, s_dd, D.lnx_w, D.lnx_b, dxn_.as<f16>(), nullptr, R)) return false; }
+        else {
+            PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.wo, d, R, d, d, dx_.as<float>(), d, D.bo, stream_));
+            PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.lnx_w, D.lnx_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
+        }
+        if (s_dd > 1) {
+            PROF(WMI_K_DEC_GEMM, w1, gemm_splitk(dxn_.as<f16>(), d, D.xq, d, R, d, d, s_dd, ws, stream_));
+            PROF(WMI_K_DEC_OTHER, (double)R * d * 2, splitk_f16(ws, s_dd, D.bxq, 0, 0.125f, dq_.as<f16>(), R, d, stream_));
+        } else {
+            PROF(WMI_K_DEC_GEMM, w1, gemm_f16(dxn_.as<f16>(), d, D.xq, d, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_));
+        }
         PROF(WMI_K_DEC_CROSS_ATTN, (double)R * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
-        PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.xo, d, R, d, d, dx_.as<float>(), d, D.bxo, stream_));
-        PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
-        PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_));
-        PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_residual(dhid_.as<f16>(), 4 * d, D.fc2, 4 * d, R, d, 4 * d, dx_.as<float>(), d, D.b2, stream_));
+        if (fused_ln) { if (!residual_ln(datt_.as<f16>(), d, D.xo, D.bxo, s_dd, D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R)) return false; }
+        else {
+            PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.xo, d, R, d, d, dx_.as<float>(), d, D.bxo, stream_));
+            PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
+        }
+        if (s_fc1 > 1) {
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_splitk(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, s_fc1, ws, stream_));
+            PROF(WMI_K_DEC_OTHER, (double)R * 4 * d * 2, splitk_f16(ws, s_fc1, D.b1, 1, 1.0f, dhid_.as<f16>(), R, 4 * d, stream_));
+        } else {
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_));
+        }
+        if (fused_ln) {
+            if (l + 1 < Ld_) { if (!residual_ln(dhid_.as<f16>(), 4 * d, D.fc2, D.b2, s_fc2, model->dec[l + 1].ln1_w, model->dec[l + 1].ln1_b, dxn_.as<f16>(), nullptr, R)) return false; }
+            else if (L > 0) { if (!residual_ln(dhid_.as<f16>(), 4 * d, D.fc2, D.b2, s_fc2, model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), d_gather, L)) return false; }
+        } else {
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_residual(dhid_.as<f16>(), 4 * d, D.fc2, 4 * d, R, d, 4 * d, dx_.as<float>(), d, D.b2, stream_));
+        }
     }
     if (L > 0) {
-        PROF(WMI_K_DEC_OTHER, (double)L * d * 6, layer_norm(dx_.as<float>(), model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), nullptr, L, d, d_gather, stream_));
+        if (!fused_ln) PROF(WMI_K_DEC_OTHER, (double)L * d * 6, layer_norm(dx_.as<float>(), model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), nullptr, L, d, d_gather, stream_));
         PROF(WMI_K_DEC_GEMM, 2.0 * Vp_ * d + 4.0 * L * Vp_, gemm_f32(dxl_.as<f16>(), d, model->d_te, d, L, Vp_, d, logits_.as<float>(), Vp_, nullptr, stream_));
         if (logits_all_out) WMI_HIP_OK(hipMemcpy2DAsync(logits_all_out, sizeof(float) * V_, logits_.p, sizeof(float) * Vp_, sizeof(float) * V_, L, hipMemcpyDeviceToHost, stream_));
         if (want_raw_logits_host) WMI_HIP_OK(hipMemcpyAsync(logits_host_.data(), logits_.as<float>() + (size_t)(L - 1) * Vp_, sizeof(float) * V_, hipMemcpyDeviceToHost, stream_));

@@ -107,6 +107,7 @@ public:
 
     // profiling
     bool profiling = false;
+    unsigned profile_mask = ~0u;        // bit per wmi_kernel_class: which classes get event pairs while profiling is on
     wmi_kernel_stat stats[WMI_K_COUNT]{};
     void collect_stats();
     void reset_stats();
@@ -139,7 +140,7 @@ private:
     int n_pages_ = 0;
     long layer_stride_ = 0;
     std::vector<int> free_pages_, page_ref_;
-    DevBuf meta_dev_, out_dev_, sample_ws_;
+    DevBuf meta_dev_, out_dev_, sample_ws_, splitk_ws_;
     PinnedBuf meta_host_, out_host_, probs_host_;
     std::vector<float> logits_host_;
     Decoder ll_dec_;                 // sequence used by whisper_decode()

@@ -349,4 +349,121 @@ bool copy_pages(f16 *kpool, f16 *vpool, long layer_stride, int n_layer, const in
     return hipGetLastError() == hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------------ split-K consumers
+// The decoder's skinny GEMMs leave fp32 partial sums ws[split][M][N]; these kernels add the splits in index
+// order and apply what the fused GEMM epilogues would have applied.
+
+__device__ __forceinline__ float gelu_f16_lut(float x) {
+    // tanh-form GELU on the f16-rounded input, rounded to f16 (the values of ggml's f16 lookup table),
+    // with the table's guards; same arithmetic as the GEMM epilogue.
+    const float h = (float)(f16)x;
+    const float u = 0.79788456080286535587989211986876f * h * (1.0f + 0.044715f * h * h);
+    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);
+    const float g = (float)(f16)(h - h * __builtin_amdgcn_rcpf(e + 1.0f));
+    return x >= 10.0f ? x : (x <= -10.0f ? 0.0f : g);
+}
+
+// One workgroup per output row i (source row m = gather ? gather[i] : i), one float4 column group per thread:
+// x[m] += bias + sum_s ws[s][m]; out[i] = LayerNorm(x[m]) with two-pass statistics (mean, then centred variance).
+// The split loads of a thread are independent, so all of them are in flight at once.
+__device__ __forceinline__ float block_sum(float v, float *red, int tid, int nwave) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                       // red may still be read from the previous reduction
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int w = 0; w < nwave; w++) t += red[w];
+    return t;
+}
+__global__ __launch_bounds__(320) void splitk_residual_ln_kernel(float *__restrict__ x, const float *__restrict__ ws, int splits, long split_stride,
+                                                                 const float *__restrict__ bias, const float *__restrict__ w, const float *__restrict__ b,
+                                                                 f16 *__restrict__ out, int d, const int *__restrict__ gather) {
+    __shared__ float red[8];
+    const int i_out = blockIdx.x, c = threadIdx.x, nch = d >> 2, nwave = blockDim.x >> 6;
+    const long m = gather ? gather[i_out] : i_out;
+    const bool on = c < nch;
+    f32x4 v = {0, 0, 0, 0};
+    if (on) {
+        const float *p = ws + m * d + 4 * c;
+        f32x4 a = *(const f32x4 *)p;
+        int s = 1;
+        for (; s + 3 < splits; s += 4) {
+            const f32x4 a0 = *(const f32x4 *)(p + s * split_stride), a1 = *(const f32x4 *)(p + (s + 1) * split_stride),
+                        a2 = *(const f32x4 *)(p + (s + 2) * split_stride), a3 = *(const f32x4 *)(p + (s + 3) * split_stride);
+            a += a0; a += a1; a += a2; a += a3;
+        }
+        for (; s < splits; s++) a += *(const f32x4 *)(p + s * split_stride);
+        f32x4 *xr = (f32x4 *)(x + m * d) + c;
+        v = *xr + (a + *(const f32x4 *)(bias + 4 * c));
+        *xr = v;
+    }
+    const float mean = block_sum(on ? (v[0] + v[1]) + (v[2] + v[3]) : 0.0f, red, c, nwave) / (float)d;
+    v -= mean;
+    const float var = block_sum(on ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.0f, red, c, nwave) / (float)d;
+    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    if (on) {
+        const f32x4 ww = *(const f32x4 *)(w + 4 * c), bb = *(const f32x4 *)(b + 4 * c);
+        f32x4 y;
+#pragma unroll
+        for (int k = 0; k < 4; k++) y[k] = v[k] * scale * ww[k] + bb[k];
+        *(f16x4 *)(out + (long)i_out * d + 4 * c) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+    }
+}
+bool splitk_residual_ln(float *x, const float *ws, int splits, const float *bias, const float *ln_w, const float *ln_b, f16 *out, int M, int d,
+                        const int *gather, int n_out, hipStream_t st) {
+    if (n_out <= 0) return true;
+    if (d % 4 != 0 || d > 1280 || splits < 1) { log_msg(2, "splitk_residual_ln: unsupported width %d\n", d); return false; }
+    const int threads = ((d / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(splitk_residual_ln_kernel, dim3(n_out), dim3(threads), 0, st, x, ws, splits, (long)M * d, bias, ln_w, ln_b, out, d, gather);
+    return hipGetLastError() == hipSuccess;
+}
+
+// out[m][n] = f16(act((sum_s ws[s][m][n] + bias[n]) * scale)), 4 columns per thread
+__global__ __launch_bounds__(256) void splitk_f16_kernel(const float *__restrict__ ws, int splits, long split_stride, const float *__restrict__ bias, int gelu, float scale,
+                                                         f16 *__restrict__ out, long n4, int N) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int n = (int)((i * 4) % N);
+    f32x4 a = *(const f32x4 *)(ws + i * 4);
+    for (int s = 1; s < splits; s++) a += *(const f32x4 *)(ws + s * split_stride + i * 4);
+    if (bias) a += *(const f32x4 *)(bias + n);
+    a *= scale;
+    if (gelu) { a[0] = gelu_f16_lut(a[0]); a[1] = gelu_f16_lut(a[1]); a[2] = gelu_f16_lut(a[2]); a[3] = gelu_f16_lut(a[3]); }
+    *(f16x4 *)(out + i * 4) = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+}
+bool splitk_f16(const float *ws, int splits, const float *bias, int gelu, float scale, f16 *out, int M, int N, hipStream_t st) {
+    if (M <= 0) return true;
+    if (N % 4 != 0 || splits < 1) return false;
+    const long n4 = (long)M * N / 4;
+    hipLaunchKernelGGL(splitk_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, splits, (long)M * N, bias, gelu, scale, out, n4, N);
+    return hipGetLastError() == hipSuccess;
+}
+
+// n in [0,d): q[m][n] = f16((sum + bias) / 8); [d,2d) / [2d,3d): K / V of row m into the paged cache at rows[m].kv_index
+__global__ __launch_bounds__(256) void splitk_dec_qkv_kernel(const float *__restrict__ ws, int splits, long split_stride, const float *__restrict__ bias,
+                                                             const DecRow *__restrict__ rows, int d, int H, f16 *__restrict__ q, f16 *__restrict__ kc, f16 *__restrict__ vc, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int N = 3 * d;
+    const int m = (int)((i * 4) / N), n = (int)((i * 4) - (long)m * N);
+    f32x4 a = *(const f32x4 *)(ws + i * 4);
+    for (int s = 1; s < splits; s++) a += *(const f32x4 *)(ws + s * split_stride + i * 4);
+    a += *(const f32x4 *)(bias + n);
+    const int part = n / d, c = n - part * d;
+    if (part == 0) {
+        *(f16x4 *)(q + (long)m * d + c) = f16x4{(f16)(a[0] * 0.125f), (f16)(a[1] * 0.125f), (f16)(a[2] * 0.125f), (f16)(a[3] * 0.125f)};
+    } else {
+        const int kv = rows[m].kv_index, page = kv / kPageTokens, off = kv % kPageTokens, h = c >> 6, e = c & 63;
+        f16 *base = part == 1 ? kc : vc;
+        *(f16x4 *)(base + (((long)page * H + h) * kPageTokens + off) * 64 + e) = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+    }
+}
+bool splitk_dec_qkv(const float *ws, int splits, const float *bias, const DecRow *rows, int M, int d, int H, f16 *q, f16 *kc, f16 *vc, hipStream_t st) {
+    if (M <= 0) return true;
+    if (d % 64 != 0 || splits < 1) return false;
+    const long n4 = (long)M * 3 * d / 4;
+    hipLaunchKernelGGL(splitk_dec_qkv_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, splits, (long)M * 3 * d, bias, rows, d, H, q, kc, vc, n4);
+    return hipGetLastError() == hipSuccess;
+}
+
 }  // namespace wmi

@@ -171,6 +171,16 @@ struct EpiDecQKV {         // q -> qbuf[m][d] * 1/8 ; k,v -> paged cache [page][
     }
 };
 
+struct EpiPartial {        // split-K partial sums: ws[split][m][n] = acc (no bias); the consumer kernel adds the splits in order
+    static constexpr bool kWide = false;
+    static constexpr bool kSplitK = true;
+    float *ws; long ld; long split_stride; int split;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { *(f32x4 *)(ws + split * split_stride + (long)m * ld + n) = a; }
+};
+
+template <class Epi, class = void> struct is_splitk { static constexpr bool value = false; };
+template <class Epi> struct is_splitk<Epi, decltype((void)Epi::kSplitK)> { static constexpr bool value = Epi::kSplitK; };
+
 // ------------------------------------------------------------------------------------------ kernel
 // Workgroup id -> output tile. Physical ids p, p+8, ... share an XCD (one private L2 each): every XCD
 // gets a contiguous run of logical ids, and logical ids walk the tile grid in groups of 8 tile rows x
@@ -260,6 +270,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
     tile_coords(blockIdx.x, (M + BM - 1) / BM, N / BN, gm, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
     const int wr = wave / WN, wc = wave % WN;
+    if constexpr (is_splitk<Epi>::value) {       // blockIdx.y = K-slice; K is the slice length
+        A += (long)blockIdx.y * K; W += (long)blockIdx.y * K;
+        epi.split = blockIdx.y;
+    }
 
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
 }
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
-static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st) {
+static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int splits = 1) {
     if (M <= 0) return true;
     if (N % BN != 0 || K % BK != 0) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (tile %dx%d)\n", M, N, K, BM, BN); return false; }
     const int nblk = ((M + BM - 1) / BM) * (N / BN);
@@ -378,7 +392,7 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
         if (hipFuncSetAttribute((const void *)gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>), dim3(nblk), dim3(64 * WM * WN), lds, st, A, lda, W, ldw, M, N, K, g_tile_group_rows, epi);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, A, lda, W, ldw, M, N, K, g_tile_group_rows, epi);
     return hipGetLastError() == hipSuccess;
 }
 
@@ -411,11 +425,108 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 10: return launch<256, 128, 4, 2, 3, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);
         case 15: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 32>(A, lda, W, ldw, M, N, K, e, st);
         case 14: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16>(A, lda, W, ldw, M, N, K, e, st);   // with per-section cycle stamps
+        case 30: return gemm_splitk(A, lda, W, ldw, M, N, K, gemm_pick_splits(M, N, K), (float *)out, st);   // the decoder's skinny path (out must hold the partials)
         case 11: return launch<256, 256, 2, 4, 2, EpiF16, 1>(A, lda, W, ldw, M, N, K, e, st);   // no global loads in the loop
         case 12: return launch<256, 256, 2, 4, 2, EpiF16, 3>(A, lda, W, ldw, M, N, K, e, st);   // no global loads, no LDS reads
         case 13: return launch<256, 256, 2, 4, 2, EpiF16, 4>(A, lda, W, ldw, M, N, K, e, st);   // no MFMA
     }
     return false;
+}
+
+// ------------------------------------------------------------------------------------------ skinny split-K GEMM
+// The decoder multiplies a few hundred activation rows with weights that are read once per pass: the job is to
+// pull the weight bytes through as many CUs as possible with as few latency round trips as possible. One
+// workgroup (4 waves, each 32 rows of a 128-row x 64-column tile) owns 64 weight rows x one K-slice of NS*64 columns:
+//   * the whole slice (<= 48 KB) is requested at once with LDS-DMA -- one HBM latency per workgroup;
+//   * activation fragments do not go through LDS at all: every lane loads its 16-byte MFMA operands for the
+//     whole slice straight from global memory (the activation panel is small and L2-resident), each wave its
+//     own 32 rows, so no activation byte is fetched twice by a workgroup;
+//   * one vmcnt(0) and one barrier publish the slice; then it is MFMAs only;
+//   * the fp32 partial tile goes to ws[split][m][n]; the consumer kernels add the splits in a fixed order.
+// Up to 8 such workgroups fit a CU, so a GEMM of 200-400 workgroups runs as one co-resident batch.
+template <int NS>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
+                                                          int M, int N, float *__restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 64, split = blockIdx.y, m0 = blockIdx.z * 128 + wave * 32;     // a wave owns 32 rows x all 64 columns
+    const long k0 = (long)split * NS * 64;
+    // weights: stage s = 64 rows x 128 B, 16-byte chunk c of row r at slot c ^ (r & 7); two DMA instructions per wave and stage
+    {
+        const int srow = lane >> 3, sslot = lane & 7;
+        const f16 *src = W + (long)(n0 + wave * 8 + srow) * ldw + k0 + ((sslot ^ srow) << 3);
+#pragma unroll
+        for (int st = 0; st < NS; st++)
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (long)p * 32 * ldw + st * 64),
+                                                 (__attribute__((address_space(3))) void *)(smem + st * 8192 + (p * 32 + wave * 8) * 128), 16, 0, 0);
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    const f16 *a_ptr = A + (long)(m0 + fr) * lda + k0 + fq * 8;
+    f16x8 fa[NS][2][2];                   // [K-step][k-half][row tile]: the wave's whole activation slice, requested at once
+#pragma unroll
+    for (int st = 0; st < NS; st++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) fa[st][ks][j] = *(const f16x8 *)(a_ptr + (long)j * 16 * lda + st * 64 + ks * 32);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): my share of the weight slice has landed (and my activations)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int st = 0; st < NS; st++) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            f16x8 fw[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = i * 16 + fr;
+                fw[i] = *(const f16x8 *)(smem + st * 8192 + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[st][ks][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float *o = ws + (long)split * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int m = m0 + j * 16 + fr, n = n0 + i * 16 + fq * 4;
+            if (m < M) *(f32x4 *)(o + (long)m * N + n) = acc[i][j];
+        }
+}
+
+// K-steps of 64 per workgroup (1..6; 0 = do not split): the largest slice that still gives >= 192 workgroups.
+static int skinny_steps(int M, int N, int K) {
+    if (N % 64 != 0 || K % BK != 0) return 0;
+    const long tiles = (long)((M + 127) / 128) * (N / 64);
+    if (tiles >= 40) return 0;           // wide outputs have enough tiles for the fused-epilogue kernels, whose activation
+                                         // traffic per weight byte is lower and which write no partial sums
+    const int nk = K / BK;
+    int pick = 0;
+    for (int ns = 6; ns >= 1; ns--)
+        if (nk % ns == 0) { pick = ns; if (tiles * (nk / ns) >= 192) break; }
+    return (nk / pick) > 1 && tiles * (nk / pick) <= 1024 ? pick : 0;      // the partial-sum workspace holds 1024 tiles
+}
+int gemm_pick_splits(int M, int N, int K) { const int ns = skinny_steps(M, N, K); return ns ? K / BK / ns : 1; }
+size_t gemm_splitk_workspace_bytes() { return (size_t)1024 * 128 * 64 * sizeof(float); }     // tiles * splits stays well under 1024 partial tiles
+bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, int splits, float *ws, hipStream_t st) {
+    const int ns = splits > 0 && K % (splits * BK) == 0 ? K / BK / splits : 0;
+    const long tiles = (long)((M + 127) / 128) * (N / 64);
+    if (ns < 1 || ns > 6 || N % 64 != 0 || tiles * splits > 1024) { log_msg(2, "gemm_splitk: bad split %d for M=%d N=%d K=%d\n", splits, M, N, K); return false; }
+    const dim3 grid(N / 64, splits, (M + 127) / 128);
+#define WMI_SKINNY(NS_) case NS_: hipLaunchKernelGGL((gemm_skinny_kernel<NS_>), grid, dim3(256), NS_ * 8192, st, A, lda, W, ldw, M, N, ws); break;
+    switch (ns) { WMI_SKINNY(1) WMI_SKINNY(2) WMI_SKINNY(3) WMI_SKINNY(4) WMI_SKINNY(5) WMI_SKINNY(6) }
+#undef WMI_SKINNY
+    return hipGetLastError() == hipSuccess;
 }
 
 bool gemm_read_stamps(unsigned long long *out, int n) {

@@ -14,6 +14,11 @@ bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int T
 bool gemm_cross_kv(const f16 *enc, const f16 *W, int M, int d, int H, int T, int Tp, int n_layer, f16 *out, const float *bias, const int *slots, hipStream_t st);
 bool gemm_dec_qkv(const f16 *xn, const f16 *W, int M, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st);
 
+// split-K path of the decoder (partials in ws, added up by the splitk_* consumers of k_decoder.hip)
+int gemm_pick_splits(int M, int N, int K);
+size_t gemm_splitk_workspace_bytes();
+bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, int splits, float *ws, hipStream_t st);
+
 extern int g_tile_group_rows;
 bool gemm_read_stamps(unsigned long long *out, int n);
 bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, hipStream_t st);
@@ -64,5 +69,10 @@ bool sample_rows(float *logits, long ld, int R, const SampleRow *srow, const Voc
                  SampleOut *out, TopkOut *topk, int topk_stride, float *probs, bool any_extra, void *workspace, hipStream_t st);
 // copy KV page contents in every layer (beam fork of a partially filled page): pairs of (src_page, dst_page)
 bool copy_pages(f16 *kpool, f16 *vpool, long layer_stride, int n_layer, const int2 *pairs, int n_pairs, int H, hipStream_t st);
+// consumers of split-K partials ws[split][M][N] (summed in split order, then the same arithmetic as the fused epilogues)
+bool splitk_residual_ln(float *x, const float *ws, int splits, const float *bias, const float *ln_w, const float *ln_b, f16 *out, int M, int d,
+                        const int *gather, int n_out, hipStream_t st);         // x[m] += sum + bias; out[i] = LN(x[gather ? gather[i] : i])
+bool splitk_f16(const float *ws, int splits, const float *bias, int gelu, float scale, f16 *out, int M, int N, hipStream_t st);
+bool splitk_dec_qkv(const float *ws, int splits, const float *bias, const DecRow *rows, int M, int d, int H, f16 *q, f16 *kc, f16 *vc, hipStream_t st);
 
 }  // namespace wmi

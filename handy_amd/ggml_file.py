@@ -49,6 +49,8 @@ ARCHS = {
     "micro.en": (51864, 128, 2, 2, 3, 80),
     "micro": (51865, 128, 2, 2, 3, 80),
     "micro-v3": (51866, 128, 2, 2, 3, 128),
+    # tiny's width with two layers each: wide enough for the decoder's split-K GEMM path (K = 384 = 6 K-steps)
+    "mini": (51865, 384, 6, 2, 2, 80),
 }
 
 

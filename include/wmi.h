@@ -68,6 +68,7 @@ WHISPER_API int wmi_bench_gemm(int M, int N, int K, int variant, int iters, floa
 enum wmi_kernel_class { WMI_K_MEL = 0, WMI_K_ENC_GEMM, WMI_K_ENC_ATTN, WMI_K_ENC_OTHER, WMI_K_DEC_GEMM, WMI_K_DEC_CROSS_ATTN, WMI_K_DEC_OTHER, WMI_K_COUNT };
 typedef struct wmi_kernel_stat { double ms; double work; long long launches; } wmi_kernel_stat;  /* work: flop (GEMM/attention) or bytes */
 WHISPER_API void wmi_set_profiling(struct whisper_state *state, int enabled);
+WHISPER_API void wmi_set_profiling_classes(struct whisper_state *state, unsigned class_mask);   /* bit k = class k; 0 turns profiling off */
 WHISPER_API int wmi_get_kernel_stats(struct whisper_state *state, wmi_kernel_stat *out /* [WMI_K_COUNT] */);
 WHISPER_API void wmi_reset_kernel_stats(struct whisper_state *state);
 

@@ -57,7 +57,7 @@ def test_mel_parity(wr, oracle, golden, model_path, arch, n_mels):
     st.free(); ctx.free(); ost.close(); om.close()
 
 
-@pytest.mark.parametrize("arch", ["micro.en", "micro-v3"])
+@pytest.mark.parametrize("arch", ["micro.en", "micro-v3", "mini"])      # "mini": d = 384, the decoder's split-K GEMMs are active
 def test_encoder_decoder_parity(wr, oracle, golden, model_path, arch):
     path = model_path(arch)
     om = oracle.OracleModel(path); ost = oracle.OracleState(om)
@@ -70,18 +70,20 @@ def test_encoder_decoder_parity(wr, oracle, golden, model_path, arch):
     err = np.abs(got - ref).max()
     print(arch, "encoder max abs err", err, "ref std", ref.std())
     assert err <= 3e-2, err                                   # fp16 activations through the stack; values are O(1)
-    assert np.abs(got[::50] - golden[f"{arch}_enc"]).max() <= 5e-2
+    if f"{arch}_enc" in golden:
+        assert np.abs(got[::50] - golden[f"{arch}_enc"]).max() <= 5e-2
     for layer in range(om.n_text_layer):
         k_ref, v_ref = ost.cross_kv(layer)
         k, v = st.cross_kv(layer)
         assert np.abs(k - k_ref).max() <= 3e-2 and np.abs(v - v_ref).max() <= 3e-2
-    toks = [int(t) for t in golden[f"{arch}_tokens"]]
+    toks = [int(t) for t in golden[f"{arch}_tokens" if f"{arch}_tokens" in golden else "micro.en_tokens"]]
     lref = ost.decode(toks, 0, 0, logits_all=True)
     lgot = st.decode_logits_all(toks, 0)
     lerr = np.abs(lgot - lref).max()
     print(arch, "logits max abs err", lerr, "std", lref.std())
     assert lerr <= 3e-2, lerr
-    assert np.abs(lgot[:, ::97] - golden[f"{arch}_logits_sub"]).max() <= 5e-2
+    if f"{arch}_logits_sub" in golden:
+        assert np.abs(lgot[:, ::97] - golden[f"{arch}_logits_sub"]).max() <= 5e-2
     # incremental decode through the paged cache equals the batched pass
     st.decode(toks[:4], 0)
     inc = np.stack([st.decode([toks[i]], i) for i in range(4, 8)])
