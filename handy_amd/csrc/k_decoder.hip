@@ -58,9 +58,39 @@ __device__ __forceinline__ void attn_merge_xor(AttnAcc &s, int mask) {
     s.m = mn;
 }
 
-__global__ __launch_bounds__(64) void dec_self_attention_kernel(const f16 *__restrict__ qb, const f16 *__restrict__ kc, const f16 *__restrict__ vc,
-                                                                const int *__restrict__ block_table, const DecRow *__restrict__ rows, int d, int H, f16 *__restrict__ att) {
-    const int head = blockIdx.x, m = blockIdx.y, lane = threadIdx.x, g = lane >> 3, e8 = lane & 7;
+// Merge of the four waves' partial states through LDS and the final store of one (row, head) output: 64 head dims by 8 threads.
+__device__ __forceinline__ void attn_block_finish(AttnAcc &s, float (*red)[8][10], int tid, f16 *dst) {
+    const int wave = tid >> 6, lane = tid & 63, g = lane >> 3, e8 = lane & 7;
+    attn_merge_xor(s, 8); attn_merge_xor(s, 16); attn_merge_xor(s, 32);
+    if (g == 0) { red[wave][e8][0] = s.m; red[wave][e8][1] = s.l;
+#pragma unroll
+        for (int i = 0; i < 8; i++) red[wave][e8][2 + i] = s.a[i]; }
+    __syncthreads();
+    if (tid < 8) {
+        float mn = -INFINITY;
+        for (int w = 0; w < 4; w++) mn = fmaxf(mn, red[w][tid][0]);
+        float l = 0.0f, a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 4; w++) {
+            const float mw = red[w][tid][0];
+            const float f = mw == -INFINITY ? 0.0f : __expf(mw - mn);
+            l += red[w][tid][1] * f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] += red[w][tid][2 + i] * f;
+        }
+        const float inv = 1.0f / l;
+        f16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = (f16)(a[i] * inv);
+        *(f16x8 *)(dst + tid * 8) = o;
+    }
+}
+
+// Causal self-attention over the paged cache: 4 waves = 32 keys per pass, two passes in flight, so a sequence of a
+// few hundred cached tokens costs a handful of dependent global-load round trips instead of one per 8 keys.
+__global__ __launch_bounds__(256) void dec_self_attention_kernel(const f16 *__restrict__ qb, const f16 *__restrict__ kc, const f16 *__restrict__ vc,
+                                                                 const int *__restrict__ block_table, const DecRow *__restrict__ rows, int d, int H, f16 *__restrict__ att) {
+    __shared__ float red[4][8][10];
+    const int head = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 3, e8 = lane & 7;
     const DecRow row = rows[m];
     const int n_kv = row.pos + 1;
     const int *bt = block_table + (long)row.seq * kMaxPagesPerSeq;
@@ -68,24 +98,22 @@ __global__ __launch_bounds__(64) void dec_self_attention_kernel(const f16 *__res
     { const f16x8 qv = *(const f16x8 *)(qb + (long)m * d + head * 64 + e8 * 8);
 #pragma unroll
       for (int i = 0; i < 8; i++) q[i] = (float)qv[i]; }
+    auto kv_off = [&](int j) { return (((long)bt[j >> 4] * H + head) * kPageTokens + (j & 15)) * 64 + e8 * 8; };
     AttnAcc s; attn_init(s);
-    for (int j = g; j < n_kv; j += 8) {
-        const int page = bt[j >> 4], off = j & 15;
-        const long o = (((long)page * H + head) * kPageTokens + off) * 64 + e8 * 8;
-        attn_step(s, q, *(const f16x8 *)(kc + o), *(const f16x8 *)(vc + o));
+    int j = wave * 8 + g;
+    for (; j + 32 < n_kv; j += 64) {
+        const long o0 = kv_off(j), o1 = kv_off(j + 32);
+        const f16x8 k0 = *(const f16x8 *)(kc + o0), v0 = *(const f16x8 *)(vc + o0);
+        const f16x8 k1 = *(const f16x8 *)(kc + o1), v1 = *(const f16x8 *)(vc + o1);
+        attn_step(s, q, k0, v0);
+        attn_step(s, q, k1, v1);
     }
-    attn_merge_xor(s, 8); attn_merge_xor(s, 16); attn_merge_xor(s, 32);
-    if (g == 0) {
-        const float inv = 1.0f / s.l;
-        f16x8 o;
-#pragma unroll
-        for (int i = 0; i < 8; i++) o[i] = (f16)(s.a[i] * inv);
-        *(f16x8 *)(att + (long)m * d + head * 64 + e8 * 8) = o;
-    }
+    for (; j < n_kv; j += 32) { const long o = kv_off(j); attn_step(s, q, *(const f16x8 *)(kc + o), *(const f16x8 *)(vc + o)); }
+    attn_block_finish(s, red, tid, att + (long)m * d + head * 64);
 }
 bool dec_self_attention(const f16 *q, const f16 *kc, const f16 *vc, const int *block_table, const DecRow *rows, int M, int d, int H, f16 *att, hipStream_t st) {
     if (M <= 0) return true;
-    hipLaunchKernelGGL(dec_self_attention_kernel, dim3(H, M), dim3(64), 0, st, q, kc, vc, block_table, rows, d, H, att);
+    hipLaunchKernelGGL(dec_self_attention_kernel, dim3(H, M), dim3(256), 0, st, q, kc, vc, block_table, rows, d, H, att);
     return hipGetLastError() == hipSuccess;
 }
 
@@ -110,28 +138,7 @@ __global__ __launch_bounds__(256) void dec_cross_attention_kernel(const f16 *__r
         attn_step(s, q, k1, v1);
     }
     for (; j < T; j += 32) attn_step(s, q, *(const f16x8 *)(kp + (long)j * 64), *(const f16x8 *)(vp + (long)j * 64));
-    attn_merge_xor(s, 8); attn_merge_xor(s, 16); attn_merge_xor(s, 32);
-    if (g == 0) { red[wave][e8][0] = s.m; red[wave][e8][1] = s.l;
-#pragma unroll
-        for (int i = 0; i < 8; i++) red[wave][e8][2 + i] = s.a[i]; }
-    __syncthreads();
-    if (tid < 8) {
-        float mn = -INFINITY;
-        for (int w = 0; w < 4; w++) mn = fmaxf(mn, red[w][tid][0]);
-        float l = 0.0f, a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int w = 0; w < 4; w++) {
-            const float mw = red[w][tid][0];
-            const float f = mw == -INFINITY ? 0.0f : __expf(mw - mn);
-            l += red[w][tid][1] * f;
-#pragma unroll
-            for (int i = 0; i < 8; i++) a[i] += red[w][tid][2 + i] * f;
-        }
-        const float inv = 1.0f / l;
-        f16x8 o;
-#pragma unroll
-        for (int i = 0; i < 8; i++) o[i] = (f16)(a[i] * inv);
-        *(f16x8 *)(att + (long)m * d + head * 64 + tid * 8) = o;
-    }
+    attn_block_finish(s, red, tid, att + (long)m * d + head * 64);
 }
 bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, int M, int d, int H, int T, int Tp, int n_layer, int layer, f16 *att, hipStream_t st) {
     if (M <= 0) return true;
