@@ -410,7 +410,7 @@ int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = -1;
     if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess &&
-        hipMalloc(&dc, std::max(Mp * N * 2 + 4096, wmi::gemm_splitk_workspace_bytes())) == hipSuccess &&      // variant 30 writes split-K partials here
+        hipMalloc(&dc, std::max(Mp * N * 4 + 4096, wmi::gemm_splitk_workspace_bytes())) == hipSuccess &&      // variant 30 writes split-K partials here, 31 fp32 rows
         hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
         hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         bool ok = true;

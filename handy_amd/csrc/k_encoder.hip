@@ -1,5 +1,6 @@
 // Encoder-side kernels for gfx950: row LayerNorm and the non-causal multi-head attention.
 #include "kernels.h"
+#include <type_traits>
 
 namespace wmi {
 
@@ -69,10 +70,16 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
                                                             f16 *__restrict__ att, int H, int T, int Tp) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];    // per stage: K tile 8 KB + V^T tile 8 KB
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    if ((int)blockIdx.x * 128 >= T) return;       // query rows that are all padding
-    const long bh = (long)b * H + head;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // Workgroup ids are dealt round-robin to the 8 XCDs (one private L2 each): give every XCD a contiguous run of
+    // logical ids, so that the query blocks of one (utterance, head), which all stream the same K and V, share an L2.
+    const int nqb = Tp / 128, nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int qblk = logical % nqb, bh_i = logical / nqb;
+    if (qblk * 128 >= T) return;                  // query rows that are all padding
+    const long bh = bh_i;
+    const int head = bh_i % H, b = bh_i / H;
+    const int q0 = qblk * 128 + wave * 32;
     const f16 *qp = Q + (bh * Tp + q0 + r) * 64 + 8 * h;
     f16x8 qf[4];
 #pragma unroll
@@ -111,7 +118,9 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     load_tile(0);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < n_tiles; kt++) {
+    // one key tile; MASK = the tile holds keys past T (only ever the last one), kept out of the steady-state loop
+    auto tile = [&](int kt, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const char *kb = smem + (kt & 1) * 16384, *vb = kb + 8192;
         if (kt + 1 < n_tiles) load_tile(kt + 1);
         f32x16 s[2];
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
                 s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kh], 0, 0, 0);
             }
         }
-        if (kt == n_tiles - 1 && (T & 63)) {          // mask keys past the end
+        if (MASK) {
 #pragma unroll
             for (int kh = 0; kh < 2; kh++)
 #pragma unroll
@@ -142,7 +151,6 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
             for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[kh][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
         const float mb = m_new * kLog2e;
         float lsum = 0.0f;
         f16x8 pf[2][2];
@@ -154,10 +162,15 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
                 lsum += p;
                 pf[kh][i >> 3][i & 7] = (f16)p;
             }
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
+        // rescale the running sums only when some query of this wave saw a new maximum (alpha == 1 exactly otherwise)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+            l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+            m_run = m_new;
+        }
+        l_run += lsum;
 #pragma unroll
         for (int kh = 0; kh < 2; kh++)
 #pragma unroll
@@ -175,7 +188,9 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
             }
         if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
         __syncthreads();
-    }
+    };
+    for (int kt = 0; kt + 1 < n_tiles; kt++) tile(kt, std::false_type{});
+    if (T & 63) tile(n_tiles - 1, std::true_type{}); else tile(n_tiles - 1, std::false_type{});
     // normalise, stage the [128 q][64 dh] tile in LDS, store whole rows
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     const int d = H * 64;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-        const int idx = p * 256 + tid, row = idx >> 3, ch = idx & 7, q = blockIdx.x * 128 + row;
+        const int idx = p * 256 + tid, row = idx >> 3, ch = idx & 7, q = qblk * 128 + row;
         if (q < T) *(f16x8 *)(att + ((long)b * T + q) * d + head * 64 + ch * 8) = *(const f16x8 *)(ob + row * 128 + ch * 16);
     }
 }
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
 bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st) {
     if (B <= 0) return true;
     if (Tp % 128 != 0 || T > Tp) { log_msg(2, "enc_attention: bad padding T=%d Tp=%d\n", T, Tp); return false; }
-    hipLaunchKernelGGL(enc_attention_kernel, dim3(Tp / 128, H, B), dim3(256), 0, st, Q, K, Vt, att, H, T, Tp);
+    hipLaunchKernelGGL(enc_attention_kernel, dim3((Tp / 128) * H * B), dim3(256), 0, st, Q, K, Vt, att, H, T, Tp);
     return hipGetLastError() == hipSuccess;
 }
 

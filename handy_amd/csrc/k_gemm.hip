@@ -50,6 +50,7 @@ struct EpiF16 {            // out[m][n] = f16(act((acc + bias) * scale))
         return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
     __device__ __forceinline__ bool wide(int n) const { return true; }
+    __device__ __forceinline__ bool wide_block(int n0, int bn) const { return true; }
     __device__ __forceinline__ void store8(int m, int n, f16x8 h) const { *(f16x8 *)(out + (long)m * ldc + n) = h; }
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { *(f16x4 *)(out + (long)m * ldc + n) = value(m, n, a); }
 };
@@ -87,6 +88,7 @@ struct EpiConv1 {          // rows have period P = 2T+2 per utterance; h1[m+1][n
         return h;
     }
     __device__ __forceinline__ bool wide(int n) const { return true; }
+    __device__ __forceinline__ bool wide_block(int n0, int bn) const { return true; }
     __device__ __forceinline__ void store8(int m, int n, f16x8 h) const { *(f16x8 *)(h1 + (long)(m + 1) * d + n) = h; }
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { *(f16x4 *)(h1 + (long)(m + 1) * d + n) = value(m, n, a); }
 };
@@ -113,6 +115,7 @@ struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -
         return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
     __device__ __forceinline__ bool wide(int n) const { return n < 2 * d; }      // the V part is stored transposed, element by element
+    __device__ __forceinline__ bool wide_block(int n0, int bn) const { return n0 + bn <= 2 * d; }
     __device__ __forceinline__ void store8(int m, int n, f16x8 o) const {
         const int b = m / T, t = m - b * T;
         const int part = n >= d, c = n - part * d, h = c >> 6, e = c & 63;
@@ -149,6 +152,7 @@ struct EpiCrossKV {        // n = (layer*2 + kv)*d + h*64 + e ; out[slot(b)][lay
         return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
     __device__ __forceinline__ bool wide(int n) const { return true; }
+    __device__ __forceinline__ bool wide_block(int n0, int bn) const { return true; }
     __device__ __forceinline__ void store8(int m, int n, f16x8 o) const { *(f16x8 *)dest(m, n) = o; }
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { *(f16x4 *)dest(m, n) = value(m, n, a); }
 };
@@ -241,6 +245,71 @@ __device__ __forceinline__ void write_tile(const Epi &epi, f32x4 (&acc)[TN][TM],
                 const int m = mw + j * 16 + fr;
                 if (m < M) epi(m, nw + i * 16 + fq * 4, acc[i][j]);
             }
+    }
+}
+
+// Output of a whole 256 x 256 workgroup tile through LDS (the 128 KB the K loop no longer needs): every wave
+// converts its accumulators to f16 (pairing lanes as in write_tile, so LDS writes are 16 bytes per lane), the tile
+// is laid out [256 rows][512 B] with 16-byte chunk c of row r at chunk c ^ (r & 7) (conflict-free for the
+// 8-lane write groups and the 16-lane read groups), and is then stored to memory as whole rows: one wave
+// instruction = 2 rows x 512 contiguous bytes. Direct stores from the accumulator layout touch 32 bytes per
+// row and instruction, which the memory side counts (and moves) as half-used 64-byte requests.
+template <class Epi>
+__device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, int wr, int wc, int wave, int lane, char *smem) {
+    const int fr = lane & 15, fq = lane >> 4;
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): my last fragment reads are done
+    __builtin_amdgcn_s_barrier();                // ... and everybody else's: the stage buffers are free
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const int rx = wr * 128 + j * 16 + fr, ry = rx + 16, cn = wc * 64 + i * 16;
+            union { f16x4 h; unsigned u[2]; } x, y;
+            x.h = epi.value(m0 + rx, n0 + cn + fq * 4, acc[i][j]);
+            y.h = epi.value(m0 + ry, n0 + cn + fq * 4, acc[i][j + 1]);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(x.u[0], y.u[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(x.u[1], y.u[1], false, false);
+            union { f16x8 h; unsigned u[4]; } o;
+            o.u[0] = s0[0]; o.u[1] = s1[0]; o.u[2] = s0[1]; o.u[3] = s1[1];
+            const int row = (fq & 1) ? ry : rx, chunk = (cn >> 3) + (fq >> 1);
+            *(f16x8 *)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = o.h;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        const int row = p * 16 + wave * 2 + (lane >> 5), chunk = lane & 31;
+        const f16x8 v = *(const f16x8 *)(smem + row * 512 + ((chunk ^ (row & 7)) << 4));
+        if (m0 + row < M) epi.store8(m0 + row, n0 + chunk * 8, v);
+    }
+}
+
+// The same for epilogues that work on fp32 values (residual add, fp32 output, ...): the raw accumulators of one
+// 128-row half at a time (128 x 256 x 4 B = 128 KB) go through LDS and come back one whole row per wave
+// instruction, so the epilogue's loads and stores are 1 KB contiguous instead of 16 rows x 64 B.
+template <class Epi>
+__device__ __forceinline__ void write_tile_staged_f32(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, int wr, int wc, int wave, int lane, char *smem) {
+    const int fr = lane & 15, fq = lane >> 4;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+        if (wr == hh) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int row = j * 16 + fr, chunk = wc * 16 + i * 4 + fq;
+                    *(f32x4 *)(smem + row * 1024 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            const int row = p * 8 + wave, m = m0 + hh * 128 + row;
+            const f32x4 v = *(const f32x4 *)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+            if (m < M) epi(m, n0 + lane * 4, v);
+        }
+        if (hh == 0) __syncthreads();
     }
 }
 
@@ -369,7 +438,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
         if (ABL & 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); t_comp += t - t_prev; t_prev = t; }
     }
-    write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
+    if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && Epi::kWide) {
+        if (epi.wide_block(n0, BN)) write_tile_staged(epi, acc, M, m0, n0, wr, wc, wave, lane, smem);
+        else write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
+    } else if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && !is_splitk<Epi>::value) {
+        write_tile_staged_f32(epi, acc, M, m0, n0, wr, wc, wave, lane, smem);
+    } else {
+        write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
+    }
     if ((ABL & 16) && blockIdx.x < 2048) {
         const unsigned long long t_issue = __builtin_amdgcn_s_memtime();
         wait_vmcnt<0>();
@@ -425,6 +501,7 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 10: return launch<256, 128, 4, 2, 3, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);
         case 15: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 32>(A, lda, W, ldw, M, N, K, e, st);
         case 14: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16>(A, lda, W, ldw, M, N, K, e, st);   // with per-section cycle stamps
+        case 31: return launch<256, 256, 2, 4, 2, EpiResidual, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);   // fp32 read-modify-write epilogue (out must hold M x N floats; bias aliased, values irrelevant)
         case 30: return gemm_splitk(A, lda, W, ldw, M, N, K, gemm_pick_splits(M, N, K), (float *)out, st);   // the decoder's skinny path (out must hold the partials)
         case 11: return launch<256, 256, 2, 4, 2, EpiF16, 1>(A, lda, W, ldw, M, N, K, e, st);   // no global loads in the loop
         case 12: return launch<256, 256, 2, 4, 2, EpiF16, 3>(A, lda, W, ldw, M, N, K, e, st);   // no global loads, no LDS reads
