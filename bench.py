@@ -47,6 +47,22 @@ def model_file(arch: str, seed: int = 0) -> str:
     return p
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the newest committed counter summary
+    (profiles/rNN_pmc_summary.json, written by scripts/pmc_bench.sh: separate rocprofv3 --pmc passes, FETCH_SIZE
+    doubled for gfx950, WRITE_SIZE as read). Counters cannot be collected from inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    rows = [r for r in json.load(open(files[-1])) if r["kernel"].startswith("gemm_nt<256x256") and r.get("fetch_MB") is not None and r.get("write_MB") is not None
+            and not r["kernel"].endswith("EpiF32>")]
+    n = sum(r["launches"] for r in rows)
+    if not n:
+        return None, None
+    return sum((r["fetch_MB"] + r["write_MB"]) * 1e6 * r["launches"] for r in rows) / n, os.path.basename(files[-1])
+
+
 def cpu_baseline(path: str, tokens: int, budget_s: float = 30.0):
     """The oracle (kind 'port': this repo's CPU restatement, not whisper.cpp) on one 30 s utterance:
     log-mel + encoder on all host threads it is given, then as many forced decode steps as fit the budget."""
@@ -90,6 +106,10 @@ def main():
     ap.add_argument("--tokens", type=int, default=128, help="decoded tokens per utterance")
     ap.add_argument("--arch", default="large-v3-turbo")
     ap.add_argument("--enc-chunk", type=int, default=int(os.environ.get("WMI_ENC_CHUNK", "16")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("WMI_BENCH_STREAMS", "1")),
+                    help="engine states per GPU, each on its own HIP stream and host thread, each transcribing --batch utterances per step")
+    ap.add_argument("--pipeline-groups", type=int, default=int(os.environ.get("WMI_PIPELINE_GROUPS", "1")),
+                    help="index ranges of the batch that decode one after the other while the encoder works on the later ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed step that profiles every kernel class")
     args = ap.parse_args()
@@ -120,8 +140,12 @@ def main():
 
     ctx = wr.WhisperContext(path, wr.WhisperContextParameters(local_rank))
     B = args.batch
-    st = ctx.create_batch_state(B, 1, args.enc_chunk)
-    st.set_force_tokens(args.tokens)
+    S = max(1, args.streams)
+    states = [ctx.create_batch_state(B, 1, args.enc_chunk) for _ in range(S)]
+    for s_ in states:
+        s_.set_force_tokens(args.tokens)
+        s_.set_pipeline_groups(args.pipeline_groups)
+    st = states[0]
     fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
     fp.set_temperature_inc(0.0)
     fp.set_no_timestamps(True)
@@ -137,11 +161,30 @@ def main():
 
     from handy_amd.node import gather_token_records, pack_token_records
 
+    import threading
+
     def step():
-        st.full_batch_device(fp, ptrs, ns)
-        rec = pack_token_records(range(rank * B, (rank + 1) * B), [st.batch_tokens(u) for u in range(B)], args.tokens + 2)
+        # S engine states run the same hot path concurrently (own stream, own host thread; ctypes drops the GIL during
+        # the call): while one state's decoder streams K/V and weights from HBM, another state's encoder keeps the MFMAs busy
+        if S == 1:
+            st.full_batch_device(fp, ptrs, ns)
+        else:
+            errs = []
+            def run(s_):
+                try:
+                    s_.full_batch_device(fp, ptrs, ns)
+                except Exception as e:      # surfaced after the join
+                    errs.append(e)
+            th = [threading.Thread(target=run, args=(s_,)) for s_ in states]
+            for t in th: t.start()
+            for t in th: t.join()
+            if errs:
+                raise errs[0]
+        recs = [pack_token_records(range((rank * S + k) * B, (rank * S + k + 1) * B), [s_.batch_tokens(u) for u in range(B)], args.tokens + 2)
+                for k, s_ in enumerate(states)]
+        rec = np.concatenate(recs, axis=0)
         if world > 1:       # the only collective on the path: gather the per-utterance token records on rank 0 (RCCL)
-            gather_token_records(rec, B, device=dev)
+            gather_token_records(rec, B * S, device=dev)
         return rec[:, 2:]
 
     for _ in range(args.warmup):
@@ -180,7 +223,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:
-        audio_s = 30.0 * B * world * args.steps
+        audio_s = 30.0 * B * S * world * args.steps
         g = stats["enc_gemm"]
         achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         per_class = None
@@ -188,15 +231,19 @@ def main():
             per_class = {k: {"ms": v["ms"], "launches": v["launches"], "rate": (v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
                          for k, v in breakdown.items()}
             per_class["_note"] = f"one extra untimed step with every kernel class under HIP events ({bd_ms:.1f} ms wall); rate in T(flop|B)/s"
+        traffic, traffic_src = pmc_traffic()
         line = {
             "metric": "RTFx (audio-sec/sec) whole node, Whisper large-v3-turbo", "value": audio_s / dt, "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"Whisper {args.arch} fp16 (synthetic ggml weights of the exact architecture), {B} x 30 s utterances per GPU per step, "
+            "config": {"workload": f"Whisper {args.arch} fp16 (synthetic ggml weights of the exact architecture), {B * S} x 30 s utterances per GPU per step"
+                                   f"{'' if S == 1 else f' ({S} concurrent engine states x {B})'}, "
                                    f"greedy, no_timestamps, {args.tokens} forced tokens per utterance, PCM resident in HBM",
-                       "utterances_per_gpu": B, "tokens_per_utterance": args.tokens, "enc_chunk": args.enc_chunk, "parallelism": f"dp{world} by utterance"},
+                       "utterances_per_gpu": B * S, "engine_states_per_gpu": S, "pipeline_groups": args.pipeline_groups, "tokens_per_utterance": args.tokens, "enc_chunk": args.enc_chunk, "parallelism": f"dp{world} by utterance"},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (encoder conv/QKV/out/MLP/cross-KV GEMMs)", "achieved": achieved,
-                         "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
+                         "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": f"bytes per launch at the L2-fabric boundary (HBM + Infinity Cache), mean over the class, from profiles/{traffic_src}" if traffic else None,
+                         "algorithmic_flop_per_launch": g["work"] / max(g["launches"], 1),
                          "avg_launch_ms": g["ms"] / max(g["launches"], 1), "launches": g["launches"]},
             "kernel_classes": per_class,
         }
@@ -206,7 +253,9 @@ def main():
             except Exception as e:      # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "audio-sec/sec", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(line))
-    st.free(); ctx.free()
+    for s_ in states:
+        s_.free()
+    ctx.free()
     if world > 1:
         dist.destroy_process_group()
 

@@ -364,6 +364,7 @@ int wmi_get_cross_kv(struct whisper_state *s, int layer, float *k, float *v) {
     Engine *e = ENG(s); return e && k && v ? e->get_cross_kv(layer, k, v) : -1;
     WMI_CATCH(-1)
 }
+void wmi_set_pipeline_groups(struct whisper_state *s, int n) { if (Engine *e = ENG(s)) e->pipeline_groups = n < 1 ? 1 : n; }
 void wmi_set_profiling(struct whisper_state *s, int on) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = on != 0; e->profile_mask = ~0u; } }
 void wmi_set_profiling_classes(struct whisper_state *s, unsigned class_mask) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = class_mask != 0; e->profile_mask = class_mask; } }
 int wmi_get_kernel_stats(struct whisper_state *s, wmi_kernel_stat *out) {
@@ -410,7 +411,7 @@ int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = -1;
     if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess &&
-        hipMalloc(&dc, std::max(Mp * N * 4 + 4096, wmi::gemm_splitk_workspace_bytes())) == hipSuccess &&      // variant 30 writes split-K partials here, 31 fp32 rows
+        hipMalloc(&dc, std::max(Mp * N * 4 + 4096, wmi::gemm_splitk_workspace_bytes((int)Mp, N))) == hipSuccess &&      // variant 30 writes split-K partials here, 31 fp32 rows
         hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
         hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         bool ok = true;

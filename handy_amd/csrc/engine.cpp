@@ -41,6 +41,10 @@ bool PinnedBuf::ensure(size_t bytes) {
 void PinnedBuf::release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 
 // ------------------------------------------------------------------------------------------ engine set-up
+// Passes of up to this many rows take the split-K path for the narrow GEMMs (the choice must not depend on the
+// number of rows below it: a sequence's arithmetic is the same whoever shares its pass).
+constexpr size_t kSplitMaxRows = 1024;
+
 Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
     max_utts_ = std::max(1, max_utts);
     max_dec_ = std::min(8, std::max(1, max_dec));
@@ -51,18 +55,23 @@ Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
     Tp_full_ = round_up(T_full_, 128);
     if (hipSetDevice(m->device) != hipSuccess) return;
     if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return;
+    if (hipStreamCreateWithFlags(&enc_stream_, hipStreamNonBlocking) != hipSuccess) return;
+    prof_stream_ = stream_;
     ok_ = alloc_workspaces();
 }
 
 Engine::~Engine() {
     (void)hipSetDevice(model->device);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (enc_stream_) (void)hipStreamSynchronize(enc_stream_);
     for (DevBuf *b : {&pcm_, &mel_raw_, &mel_max_, &mel_utt_dev_, &mel_norm_tmp_, &melT_, &h1_, &x_, &xn_, &q_, &k_, &vt_, &att_, &hid_, &enc16_, &enc32_,
-                      &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_, &sample_ws_})
+                      &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_, &sample_ws_, &splitk_ws_})
         b->release();
-    meta_host_.release(); out_host_.release(); probs_host_.release();
+    meta_host_.release(); out_host_.release(); probs_host_.release(); win_host_.release(); slots_host_.release();
+    for (hipEvent_t e : enc_events_) (void)hipEventDestroy(e);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (stream_) (void)hipStreamDestroy(stream_);
+    if (enc_stream_) (void)hipStreamDestroy(enc_stream_);
 }
 
 bool Engine::alloc_workspaces() {
@@ -78,7 +87,9 @@ bool Engine::alloc_workspaces() {
     ok &= enc16_.ensure(Mp * d * sizeof(f16));
     const size_t qkv = (size_t)E * H_ * Tp_full_ * 64 * sizeof(f16);
     ok &= q_.ensure(qkv); ok &= k_.ensure(qkv); ok &= vt_.ensure(qkv);
-    ok &= win_dev_.ensure(sizeof(WinDesc) * E); ok &= slots_dev_.ensure(sizeof(int) * E);
+    ring_cap_ = 2 * max_utts_ + 4 * E;       // more than everything that can be queued at once, even after a wrap
+    ok &= win_dev_.ensure(sizeof(WinDesc) * ring_cap_); ok &= slots_dev_.ensure(sizeof(int) * ring_cap_);
+    ok &= win_host_.ensure(sizeof(WinDesc) * ring_cap_); ok &= slots_host_.ensure(sizeof(int) * ring_cap_);
     ok &= ckv_.ensure((size_t)max_utts_ * Ld_ * 2 * H_ * Tp_full_ * 64 * sizeof(f16));
     ok &= mel_max_.ensure(sizeof(unsigned) * max_utts_); ok &= mel_utt_dev_.ensure(sizeof(MelUtt) * max_utts_);
     // self-attention KV pool: pages of 16 tokens, shared by every sequence through block tables
@@ -102,7 +113,6 @@ bool Engine::alloc_workspaces() {
     ok &= out_dev_.ensure((size_t)lrows_cap_ * (sizeof(SampleOut) + 8 * sizeof(TopkOut)));
     ok &= out_host_.ensure((size_t)lrows_cap_ * (sizeof(SampleOut) + 8 * sizeof(TopkOut)));
     ok &= sample_ws_.ensure(sample_workspace_bytes(lrows_cap_));
-    ok &= splitk_ws_.ensure(gemm_splitk_workspace_bytes());
     logits_host_.assign(V_, 0.0f);
     ok &= ensure_rows(std::max(128, max_seqs));
     return ok;
@@ -115,6 +125,7 @@ bool Engine::ensure_rows(int rows) {
               datt_.ensure(R * d_ * sizeof(f16)) && dhid_.ensure(R * 4 * d_ * sizeof(f16));
     const size_t meta = R * sizeof(DecRow) + (size_t)lrows_cap_ * (sizeof(SampleRow) + sizeof(int) * (kMaxPagesPerSeq + 1)) + R * sizeof(int2) + 4096;
     ok = ok && meta_dev_.ensure(meta) && meta_host_.ensure(meta);
+    ok = ok && splitk_ws_.ensure(gemm_splitk_workspace_bytes((int)std::min<size_t>(R, kSplitMaxRows), d_), false);
     if (ok) rows_cap_ = (int)R;
     return ok;
 }
@@ -129,12 +140,12 @@ void Engine::prof_begin(int cls, double work) {
     }
     EvPair &e = ev_pool_[ev_used_];
     e.cls = cls; e.work = work;
-    (void)hipEventRecord(e.a, stream_);
+    (void)hipEventRecord(e.a, prof_stream_);
     prof_open_ = true;
 }
 void Engine::prof_end() {
     if (!profiling || !prof_open_) return;
-    (void)hipEventRecord(ev_pool_[ev_used_].b, stream_);
+    (void)hipEventRecord(ev_pool_[ev_used_].b, prof_stream_);
     ev_used_++;
     prof_open_ = false;
     if (ev_used_ >= 200000) collect_stats();
@@ -142,6 +153,7 @@ void Engine::prof_end() {
 void Engine::collect_stats() {
     if (!ev_used_) return;
     (void)hipStreamSynchronize(stream_);
+    (void)hipStreamSynchronize(enc_stream_);
     for (size_t i = 0; i < ev_used_; i++) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b) == hipSuccess) {
@@ -234,15 +246,32 @@ int Engine::get_mel(int utt, float *out, int n_frames) {
 }
 
 // ------------------------------------------------------------------------------------------ encoder
-bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32) {
+hipEvent_t Engine::next_enc_event() {
+    if (enc_events_used_ == enc_events_.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        enc_events_.push_back(e);
+    }
+    return enc_events_[enc_events_used_++];
+}
+
+bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32, hipStream_t stream_) {
+    // (the parameter shadows the member on purpose: every launch below goes to the caller's stream)
     const int E = (int)wins.size(), d = d_, T2 = 2 * T, Tp = Tp_full_;
     if (E <= 0) return true;
     if (E > enc_chunk_ || T <= 0 || T > T_full_) return false;
-    WMI_HIP_OK(hipMemcpyAsync(win_dev_.p, wins.data(), sizeof(WinDesc) * E, hipMemcpyHostToDevice, stream_));
-    WMI_HIP_OK(hipMemcpyAsync(slots_dev_.p, slots.data(), sizeof(int) * E, hipMemcpyHostToDevice, stream_));
+    prof_stream_ = stream_;
+    // chunk metadata goes through a pinned ring: the copy is asynchronous and a later chunk must not overwrite it
+    if (ring_pos_ + E > ring_cap_) ring_pos_ = 0;
+    WinDesc *hw = win_host_.as<WinDesc>() + ring_pos_, *dw = win_dev_.as<WinDesc>() + ring_pos_;
+    int *hs = slots_host_.as<int>() + ring_pos_, *ds = slots_dev_.as<int>() + ring_pos_;
+    ring_pos_ += E;
+    memcpy(hw, wins.data(), sizeof(WinDesc) * E); memcpy(hs, slots.data(), sizeof(int) * E);
+    WMI_HIP_OK(hipMemcpyAsync(dw, hw, sizeof(WinDesc) * E, hipMemcpyHostToDevice, stream_));
+    WMI_HIP_OK(hipMemcpyAsync(ds, hs, sizeof(int) * E, hipMemcpyHostToDevice, stream_));
     const double win_bytes = (double)E * T2 * n_mel_ * 6;
-    if (mel_user_) PROF(WMI_K_ENC_OTHER, win_bytes, mel_window_normalized(mel_raw_.as<float>(), win_dev_.as<WinDesc>(), E, n_mel_, T2, melT_.as<f16>(), stream_));
-    else PROF(WMI_K_ENC_OTHER, win_bytes, mel_window(mel_raw_.as<float>(), mel_max_.as<unsigned>(), win_dev_.as<WinDesc>(), E, n_mel_, T2, melT_.as<f16>(), stream_));
+    if (mel_user_) PROF(WMI_K_ENC_OTHER, win_bytes, mel_window_normalized(mel_raw_.as<float>(), dw, E, n_mel_, T2, melT_.as<f16>(), stream_));
+    else PROF(WMI_K_ENC_OTHER, win_bytes, mel_window(mel_raw_.as<float>(), mel_max_.as<unsigned>(), dw, E, n_mel_, T2, melT_.as<f16>(), stream_));
     const int M1 = E * (T2 + 2), M2 = E * (T + 1), M = E * T;
     const int K1 = 3 * n_mel_;
     PROF(WMI_K_ENC_GEMM, 2.0 * E * T2 * d * K1, gemm_conv1(melT_.as<f16>(), n_mel_, model->conv1_w, model->conv1_kpad, M1, d, h1_.as<f16>(), model->conv1_b, T2, stream_));
@@ -262,7 +291,8 @@ bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<in
     if (want_f32) { if (!enc32_.ensure((size_t)round_up(M, 256) * d * sizeof(float))) return false; e32 = enc32_.as<float>(); }
     PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(x_.as<float>(), model->ln_post_w, model->ln_post_b, enc16_.as<f16>(), e32, M, d, nullptr, stream_));
     PROF(WMI_K_ENC_GEMM, 2.0 * M * (2.0 * Ld_ * d) * d,
-         gemm_cross_kv(enc16_.as<f16>(), model->xkv_w, M, d, H_, T, Tp, Ld_, ckv_.as<f16>(), model->xkv_b, slots_dev_.as<int>(), stream_));
+         gemm_cross_kv(enc16_.as<f16>(), model->xkv_w, M, d, H_, T, Tp, Ld_, ckv_.as<f16>(), model->xkv_b, ds, stream_));
+    prof_stream_ = this->stream_;
     enc_T_ = T;
     n_encode += E;
     return true;
@@ -275,7 +305,7 @@ int Engine::encode(int offset, int audio_ctx) {
     if (T > T_full_) return -1;
     const double t0 = now_ms();
     WinDesc w{mel_utt_[0].mel_off, mel_utt_[0].n_frames, utt_n_len_[0], offset, 0};
-    if (!encode_chunk({w}, {0}, T, true)) return -1;
+    if (!encode_chunk({w}, {0}, T, true, stream_)) return -1;
     if (hipStreamSynchronize(stream_) != hipSuccess) return -1;
     t_encode_ms += now_ms() - t0;
     return 0;
@@ -362,7 +392,10 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     // Skinny GEMMs go through split-K (partials in splitk_ws_, summed by the consumer that also applies the
     // epilogue and, for the residual GEMMs, the LayerNorm that follows); wide passes use the fused epilogues.
     float *ws = splitk_ws_.as<float>();
-    const int s_qkv = gemm_pick_splits(R, 3 * d, d), s_dd = gemm_pick_splits(R, d, d), s_fc1 = gemm_pick_splits(R, 4 * d, d), s_fc2 = gemm_pick_splits(R, d, 4 * d);
+    const bool may_split = (size_t)R <= kSplitMaxRows;
+    const int s_qkv = may_split ? gemm_pick_splits(3 * d, d) : 1, s_dd = may_split ? gemm_pick_splits(d, d) : 1,
+              s_fc1 = may_split ? gemm_pick_splits(4 * d, d) : 1, s_fc2 = may_split ? gemm_pick_splits(d, 4 * d) : 1;
+    prof_stream_ = stream_;
     const bool fused_ln = s_dd > 1 && s_fc2 > 1;      // x += ... and the next LayerNorm in one kernel
     auto residual_ln = [&](const f16 *a, int K, const f16 *Wt, const float *bias, int splits, const float *lw, const float *lb, f16 *out, const int *gather, int n_out) -> bool {
         PROF(WMI_K_DEC_GEMM, 2.0 * d * K, gemm_splitk(a, K, Wt, K, R, d, K, splits, ws, stream_));
@@ -828,10 +861,14 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
 
     std::vector<DecRow> rows; std::vector<SampleRow> srows; std::vector<const Decoder *> seqs; std::vector<int2> copies;
     std::vector<PassRowRef> lref;
+    std::vector<char> in_pass, gated;
+    E.enc_events_used_ = 0;
     int rc = 0;
     for (;;) {
         if (single && P.abort_callback && P.abort_callback(P.abort_callback_user_data)) { rc = -6; break; }
-        // ---- encoder for every utterance that needs a window
+        // ---- encoder for every utterance that needs a window: queued on the encoder stream, not waited for. Each chunk
+        //      is followed by an event; an utterance joins decoder passes once its chunk's event has completed, so the
+        //      decoder passes of earlier chunks (HBM-bound) run beside the encoder GEMMs of later ones (MFMA-bound).
         std::vector<int> need;
         for (int i = 0; i < G; i++) {
             Utt &u = utts[i];
@@ -842,7 +879,7 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
             t0 = now_ms();
             const int T = P.audio_ctx > 0 ? P.audio_ctx : M.hp.n_audio_ctx;
             for (size_t c0 = 0; c0 < need.size() && rc == 0; c0 += E.enc_chunk_) {
-                std::vector<WinDesc> wins; std::vector<int> slots;
+                std::vector<WinDesc> wins; std::vector<int> slots; std::vector<int> members;
                 for (size_t c = c0; c < std::min(need.size(), c0 + (size_t)E.enc_chunk_); c++) {
                     Utt &u = utts[need[c]];
                     if (single && u.phase == Phase::Encode) {
@@ -852,9 +889,14 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
                     const MelUtt &mu = E.mel_utt_[u.mel_idx];
                     wins.push_back(WinDesc{mu.mel_off, mu.n_frames, u.n_len, u.seek, u.mel_idx});
                     slots.push_back(u.slot);
+                    members.push_back(need[c]);
                 }
+                if (wins.empty()) continue;
                 // language detection always uses the full audio context
-                if (!E.encode_chunk(wins, slots, T, false)) rc = -6;
+                if (!E.encode_chunk(wins, slots, T, false, E.enc_stream_)) { rc = -6; break; }
+                hipEvent_t ev = E.next_enc_event();
+                if (!ev || hipEventRecord(ev, E.enc_stream_) != hipSuccess) { rc = -6; break; }
+                for (int i : members) utts[i].enc_ev = ev;
             }
             if (rc) break;
             for (int i : need) {
@@ -862,13 +904,42 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
                 if (u.phase == Phase::LangEncode) { u.encoded_at_seek = true; u.phase = Phase::LangDecode; }
                 else if (u.phase == Phase::Encode) begin_window(u);
             }
-            E.t_encode_ms += now_ms() - t0;       // launch time only; the stream is drained by the decoder pass below
+            E.t_encode_ms += now_ms() - t0;       // launch time only
         }
-        // ---- one decoder pass over every sequence that wants logits
+        // ---- which utterances can decode now: those whose encoder chunk has completed and whose pipeline group is open.
+        //      The batch is cut into E.pipeline_groups index ranges; a group decodes once every earlier group is finished,
+        //      so decoder passes stay full (a pass costs nearly the same for 16 rows as for 64: it streams all the weights)
+        //      while the encoder is still busy with the later groups.
+        const int n_groups = std::max(1, std::min(E.pipeline_groups, G));
+        int open_group = n_groups;
+        for (int i = 0; i < G; i++) if (utts[i].phase != Phase::Done) { open_group = (int)((long)i * n_groups / G); break; }
+        bool any_ready = false, any_pending = false;
+        hipEvent_t first_pending = nullptr;
+        gated.assign(G, 0);
+        for (int i = 0; i < G; i++) {
+            Utt &u = utts[i];
+            if (u.phase != Phase::LangDecode && u.phase != Phase::Prompt && u.phase != Phase::Step) continue;
+            if ((int)((long)i * n_groups / G) > open_group) { gated[i] = 1; continue; }
+            if (u.enc_ev) {
+                const hipError_t q = hipEventQuery(u.enc_ev);
+                if (q == hipSuccess) u.enc_ev = nullptr;
+                else if (q == hipErrorNotReady) { any_pending = true; if (!first_pending) first_pending = u.enc_ev; }
+                else { rc = -6; break; }
+            }
+            if (!u.enc_ev) any_ready = true;
+        }
+        if (rc) break;
+        if (!any_ready && any_pending) {           // nothing to decode yet: wait for the oldest chunk in the queue
+            if (hipEventSynchronize(first_pending) != hipSuccess) { rc = -6; break; }
+            continue;
+        }
+        // ---- one decoder pass over every ready sequence that wants logits
         rows.clear(); srows.clear(); seqs.clear(); copies.clear(); lref.clear();
+        in_pass.assign(G, 0);
         bool fail = false;
         for (int i = 0; i < G && !fail; i++) {
             Utt &u = utts[i];
+            if (u.enc_ev || gated[i]) continue;
             if (u.phase == Phase::LangDecode) {
                 Decoder &d = u.dec[0];
                 E.page_release(d.pages); d.n_kv = 0;
@@ -876,6 +947,7 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
                 if (!E.append_kv_slot(d, 0, copies, r.kv_index)) { fail = true; break; }
                 SampleRow s{}; s.flags = 256; s.max_initial = -1; s.topk = 0;
                 rows.push_back(r); srows.push_back(s); seqs.push_back(&d); lref.push_back({i, -1});
+                in_pass[i] = 1;
             } else if (u.phase == Phase::Prompt) {
                 Decoder &d = u.dec[0];
                 const int sidx = (int)seqs.size();
@@ -886,6 +958,7 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
                     if (t == u.n_prompt - 1) { r.logit_row = (int)srows.size(); srows.push_back(sample_state(u, d)); lref.push_back({i, 0}); }
                     rows.push_back(r);
                 }
+                in_pass[i] = 1;
             } else if (u.phase == Phase::Step) {
                 for (int j = 0; j < u.n_cur; j++) {
                     Decoder &d = u.dec[j];
@@ -897,6 +970,7 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
                     rows.push_back(r); seqs.push_back(&d); lref.push_back({i, j});
                 }
                 u.i++;
+                in_pass[i] = 1;
             }
         }
         if (fail) { rc = -8; break; }
@@ -915,9 +989,10 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
             for (int c = 0; c < 8; c++) d.topk[c] = tk[lr * 8 + c];
             if (srows[lr].want_probs) d.probs.assign(E.probs_host_.as<float>() + lr * (size_t)E.V_, E.probs_host_.as<float>() + (lr + 1) * (size_t)E.V_);
         }
-        // ---- advance the state machines
+        // ---- advance the state machines of the utterances that were in the pass
         for (int i = 0; i < G; i++) {
             Utt &u = utts[i];
+            if (!in_pass[i]) continue;
             if (u.phase == Phase::LangDecode) {
                 // raw logits of this row are still on the device: fetch the language slice
                 int lrow = -1;
@@ -944,6 +1019,7 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
             }
         }
     }
+    if (rc) (void)hipStreamSynchronize(E.enc_stream_);        // an early exit must not leave encoder work behind the caller's back
     for (Utt &u : utts) { release_decoders(u); if (u.rc != 0) { E.results[u.index].rc = u.rc; if (!rc) rc = u.rc; } }
     return rc;
 }

@@ -72,6 +72,7 @@ struct Utt {
     int lang_id = 0;
     bool no_timestamps = false;
     bool encoded_at_seek = false; // the cross K/V in the slot already belong to window `seek`
+    hipEvent_t enc_ev = nullptr; // recorded on the encoder stream behind this utterance's chunk; cleared once seen complete
     int rc = 0;
 };
 
@@ -102,6 +103,7 @@ public:
     Model *model;
     std::vector<UttResult> results;
     int force_tokens = 0;
+    int pipeline_groups = 1;             // index ranges of a batch that decode one after the other while later ones still encode
     bool beam_sampled = false;
     int exp_n_audio_ctx = 0;
 
@@ -118,7 +120,9 @@ public:
 private:
     bool ok_ = false;
     int max_utts_, max_dec_, enc_chunk_;
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr;       // decoder passes, log-mel, the low-level whisper_encode/decode calls
+    hipStream_t enc_stream_ = nullptr;   // encoder chunks of whisper_full: they run beside the decoder passes of earlier chunks
+    hipStream_t prof_stream_ = nullptr;  // where the profiling events of the kernels being launched go
     int d_, H_, Le_, Ld_, T_full_, n_mel_, V_, Vp_;
 
     // mel
@@ -129,6 +133,11 @@ private:
 
     // encoder workspace
     DevBuf melT_, h1_, x_, xn_, q_, k_, vt_, att_, hid_, enc16_, enc32_, win_dev_, slots_dev_;
+    PinnedBuf win_host_, slots_host_;    // per-chunk metadata: a ring, so that several chunks can be queued before the first one runs
+    int ring_pos_ = 0, ring_cap_ = 0;
+    std::vector<hipEvent_t> enc_events_; // pool of encoder-chunk completion events
+    size_t enc_events_used_ = 0;
+    hipEvent_t next_enc_event();
     int enc_T_ = 0;                  // audio context of the last encode (cross K/V length)
     DevBuf ckv_;
     int Tp_full_ = 0;
@@ -156,7 +165,7 @@ private:
     bool alloc_workspaces();
     bool ensure_rows(int rows);
     bool compute_mel(const float *pcm_dev_base, const std::vector<long> &offs, const std::vector<int> &n);
-    bool encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32);
+    bool encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32, hipStream_t s);
     struct PassOut { std::vector<SampleOut> so; std::vector<TopkOut> topk; };
     bool decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow> &srows, const std::vector<const Decoder *> &seqs,
                       const std::vector<int2> &page_copies, int T, bool want_raw_logits_host, float *logits_all_out);

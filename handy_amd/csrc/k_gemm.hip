@@ -323,7 +323,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // groups instead of in one burst after the barrier; kFirstHalf confines that to the first k-half of the step,
 // so the loads get the second half's MFMAs as extra time to land. Harness-only builds: kNoLoads / kNoLdsReads /
 // kNoMfma drop one ingredient of the loop (ablation timing), kStamps records s_memtime per loop section.
-enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32 };
+enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
 
     // --- staging: one LDS-DMA wave-instruction moves 8 rows x 128 B
     const int srow = lane >> 3, sslot = lane & 7;
-    const f16 *a_src = A + (long)(m0 + wave * 8 + srow) * lda + ((sslot ^ srow) << 3);      // (row & 7) == srow for every piece
-    const f16 *w_src = W + (long)(n0 + wave * 8 + srow) * ldw + ((sslot ^ srow) << 3);
+    const f16 *a_src = A + (long)(((ABL & kSameTile) ? 0 : m0) + wave * 8 + srow) * lda + ((sslot ^ srow) << 3);      // (row & 7) == srow for every piece
+    const f16 *w_src = W + (long)(((ABL & kSameTile) ? 0 : n0) + wave * 8 + srow) * ldw + ((sslot ^ srow) << 3);
     auto stage = [&](int kt, int buf) {
         char *base = smem + buf * STAGE + wave * 1024;
 #pragma unroll
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
                 }
             }
             if (ABL & 4) {
+                if ((ABL & kSpread) && !(ABL & kNoLoads) && more && ks == 0) stage(kt + NST - 1, nbuf);
 #pragma unroll
                 for (int j = 0; j < TM; j++) asm volatile("" ::"v"(fa[j]));
 #pragma unroll
@@ -502,7 +503,12 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 15: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 32>(A, lda, W, ldw, M, N, K, e, st);
         case 14: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16>(A, lda, W, ldw, M, N, K, e, st);   // with per-section cycle stamps
         case 31: return launch<256, 256, 2, 4, 2, EpiResidual, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);   // fp32 read-modify-write epilogue (out must hold M x N floats; bias aliased, values irrelevant)
-        case 30: return gemm_splitk(A, lda, W, ldw, M, N, K, gemm_pick_splits(M, N, K), (float *)out, st);   // the decoder's skinny path (out must hold the partials)
+        case 30: return gemm_splitk(A, lda, W, ldw, M, N, K, gemm_pick_splits(N, K), (float *)out, st);   // the decoder's skinny path (out must hold the partials)
+        case 22: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, e, st);   // loads + MFMA, fragments read once
+        case 23: return launch<256, 256, 2, 4, 2, EpiF16, kNoLoads | kNoMfma>(A, lda, W, ldw, M, N, K, e, st);                   // LDS fragment reads only
+        case 24: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kNoMfma | kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, e, st);   // loads only
+        case 25: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kNoMfma | kSpread | kFirstHalf | kSameTile>(A, lda, W, ldw, M, N, K, e, st);   // loads only, all L2 hits
+        case 26: return launch<256, 256, 2, 4, 2, EpiF16, kSpread | kFirstHalf | kSameTile>(A, lda, W, ldw, M, N, K, e, st);                          // full loop, all L2 hits
         case 11: return launch<256, 256, 2, 4, 2, EpiF16, 1>(A, lda, W, ldw, M, N, K, e, st);   // no global loads in the loop
         case 12: return launch<256, 256, 2, 4, 2, EpiF16, 3>(A, lda, W, ldw, M, N, K, e, st);   // no global loads, no LDS reads
         case 13: return launch<256, 256, 2, 4, 2, EpiF16, 4>(A, lda, W, ldw, M, N, K, e, st);   // no MFMA
@@ -581,24 +587,25 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const f16 *__restrict_
         }
 }
 
-// K-steps of 64 per workgroup (1..6; 0 = do not split): the largest slice that still gives >= 192 workgroups.
-static int skinny_steps(int M, int N, int K) {
+// K-steps of 64 per workgroup (1..6; 0 = do not split): the largest slice that still gives >= 192 workgroups for one
+// 128-row panel. The choice depends on the weight shape only, never on the number of rows, so a sequence's numbers do
+// not depend on what else shares its pass (more rows just add grid.z panels).
+static int skinny_steps(int N, int K) {
     if (N % 64 != 0 || K % BK != 0) return 0;
-    const long tiles = (long)((M + 127) / 128) * (N / 64);
+    const int tiles = N / 64;
     if (tiles >= 40) return 0;           // wide outputs have enough tiles for the fused-epilogue kernels, whose activation
                                          // traffic per weight byte is lower and which write no partial sums
     const int nk = K / BK;
     int pick = 0;
     for (int ns = 6; ns >= 1; ns--)
-        if (nk % ns == 0) { pick = ns; if (tiles * (nk / ns) >= 192) break; }
-    return (nk / pick) > 1 && tiles * (nk / pick) <= 1024 ? pick : 0;      // the partial-sum workspace holds 1024 tiles
+        if (nk % ns == 0 && nk / ns <= 16) { pick = ns; if (tiles * (nk / ns) >= 192) break; }
+    return pick && (nk / pick) > 1 ? pick : 0;
 }
-int gemm_pick_splits(int M, int N, int K) { const int ns = skinny_steps(M, N, K); return ns ? K / BK / ns : 1; }
-size_t gemm_splitk_workspace_bytes() { return (size_t)1024 * 128 * 64 * sizeof(float); }     // tiles * splits stays well under 1024 partial tiles
+int gemm_pick_splits(int N, int K) { const int ns = skinny_steps(N, K); return ns ? K / BK / ns : 1; }
+size_t gemm_splitk_workspace_bytes(int rows, int n) { return (size_t)16 * rows * n * sizeof(float); }     // splits <= 16 by construction (K <= 6144)
 bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, int splits, float *ws, hipStream_t st) {
     const int ns = splits > 0 && K % (splits * BK) == 0 ? K / BK / splits : 0;
-    const long tiles = (long)((M + 127) / 128) * (N / 64);
-    if (ns < 1 || ns > 6 || N % 64 != 0 || tiles * splits > 1024) { log_msg(2, "gemm_splitk: bad split %d for M=%d N=%d K=%d\n", splits, M, N, K); return false; }
+    if (ns < 1 || ns > 6 || N % 64 != 0 || splits > 16) { log_msg(2, "gemm_splitk: bad split %d for M=%d N=%d K=%d\n", splits, M, N, K); return false; }
     const dim3 grid(N / 64, splits, (M + 127) / 128);
 #define WMI_SKINNY(NS_) case NS_: hipLaunchKernelGGL((gemm_skinny_kernel<NS_>), grid, dim3(256), NS_ * 8192, st, A, lda, W, ldw, M, N, ws); break;
     switch (ns) { WMI_SKINNY(1) WMI_SKINNY(2) WMI_SKINNY(3) WMI_SKINNY(4) WMI_SKINNY(5) WMI_SKINNY(6) }

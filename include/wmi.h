@@ -43,6 +43,10 @@ WHISPER_API int wmi_batch_n_fallbacks(struct whisper_state *state, int utt);
  * tokens long -- the end-of-text token is masked before position n and forced at it. Synthetic
  * audio and random weights have no natural transcript length; this fixes the decode workload. */
 WHISPER_API void wmi_set_force_tokens(struct whisper_state *state, int n);
+/* Encoder/decoder overlap inside one wmi_full_batch call: the batch is cut into n index ranges; range k decodes (HBM-bound)
+ * while the encoder (MFMA-bound) is still working on ranges k+1.. on a second stream. 1 = encode everything first. Results do
+ * not depend on n. */
+WHISPER_API void wmi_set_pipeline_groups(struct whisper_state *state, int n);
 /* Beam-search candidate rule: 0 = deterministic k most probable tokens per beam (default),
  * 1 = k draws from the token distribution with a per-decoder mt19937 (what upstream does). */
 WHISPER_API void wmi_set_beam_candidates_sampled(struct whisper_state *state, int sampled);

@@ -1,0 +1,38 @@
+"""Log-mel roofline probe: one hour of synthetic 16 kHz audio (120 x 30 s) resident in HBM -> raw log-mel, 80 and 128 bins.
+Times wmi_mel_batch_device with HIP-side synchronisation and prints achieved GB/s on the algorithmic bytes
+(PCM in + fp32 log-mel out for the 3000 frames that see audio and the 3000 frames of zero tail)."""
+import ctypes as C, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from handy_amd import whisper_rs as wr, ggml_file as gf
+from handy_amd.synth import synth_pcm
+
+L = wr.load_library()
+L.wmi_mel_batch_device.restype = C.c_int
+L.wmi_mel_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_int]
+dev = torch.device("cuda", 0)
+B, n = 120, 480000
+pool = np.stack([synth_pcm(i, n) for i in range(8)])
+pcm = torch.from_numpy(pool).to(dev).repeat(B // 8, 1).contiguous()
+out = []
+for arch, n_mel in (("micro.en", 80), ("micro-v3", 128)):
+    path = f"/tmp/wmi_mel_probe_{arch}.bin"
+    if not os.path.exists(path):
+        gf.write_synthetic_model(path, arch, seed=0)
+    ctx = wr.WhisperContext(path); st = ctx.create_batch_state(B, 1, 4)
+    offs = (C.c_longlong * B)(*[i * n for i in range(B)]); ns = (C.c_int * B)(*([n] * B))
+    call = lambda: L.wmi_mel_batch_device(ctx.h, st.h, C.c_void_p(pcm.data_ptr()), offs, ns, B)
+    assert call() == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); reps = 20
+    for _ in range(reps):
+        assert call() == 0
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    n_frames = (n + 480000) // 160
+    bytes_alg = B * (n * 4 + n_mel * n_frames * 4)
+    out.append({"n_mel": n_mel, "audio_hours": B * 30 / 3600, "ms": dt * 1e3, "GBps": bytes_alg / dt / 1e9, "frac_of_8TBps": bytes_alg / dt / 8e12,
+                "rtfx": B * 30 / dt, "algorithmic_MB": bytes_alg / 1e6})
+    st.free(); ctx.free()
+print(json.dumps({"probe": "log-mel frontend, 1 h of 16 kHz audio resident in HBM", "results": out}))

@@ -148,6 +148,25 @@ def test_batch_equals_single_and_ragged_inputs(wr, model_path):
     bst.free(); st.free(); ctx.free()
 
 
+def test_pipeline_groups_do_not_change_results(wr, model_path):
+    """Decoding index ranges of the batch one after the other while the encoder stream still works on the later ones
+    (wmi_set_pipeline_groups) changes which sequences share a decoder pass, never their tokens."""
+    path = model_path("mini", decisive=4.0)
+    ctx = wr.WhisperContext(path)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language("en")
+    pcms = [synth_pcm(200 + i, n) for i, n in enumerate((480000, 200000, 330000, 480000, 64000, 700000, 480000, 120000, 480000, 250000))]
+    runs = []
+    for groups in (1, 3, 10):
+        st = ctx.create_batch_state(len(pcms), 1, 2)
+        st.set_pipeline_groups(groups)
+        st.full_batch(fp, pcms)
+        runs.append([st.batch_tokens(u) for u in range(len(pcms))])
+        st.free()
+    assert runs[0] == runs[1] == runs[2]
+    assert sum(len(t) for t in runs[0]) > 100
+    ctx.free()
+
+
 def test_language_detection_and_engine_mirror(wr, oracle, model_path):
     path = model_path("micro", decisive=4.0)
     om = oracle.OracleModel(path); ost = oracle.OracleState(om)
