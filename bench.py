@@ -110,6 +110,7 @@ def main():
                     help="engine states per GPU, each on its own HIP stream and host thread, each transcribing --batch utterances per step")
     ap.add_argument("--pipeline-groups", type=int, default=int(os.environ.get("WMI_PIPELINE_GROUPS", "1")),
                     help="index ranges of the batch that decode one after the other while the encoder works on the later ones")
+    ap.add_argument("--encoder-lanes", type=int, default=int(os.environ.get("WMI_ENCODER_LANES", "1")), help="2: alternate encoder chunks between two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed step that profiles every kernel class")
     args = ap.parse_args()
@@ -145,6 +146,7 @@ def main():
     for s_ in states:
         s_.set_force_tokens(args.tokens)
         s_.set_pipeline_groups(args.pipeline_groups)
+        s_.set_encoder_lanes(args.encoder_lanes)
     st = states[0]
     fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
     fp.set_temperature_inc(0.0)
@@ -239,7 +241,7 @@ def main():
             "config": {"workload": f"Whisper {args.arch} fp16 (synthetic ggml weights of the exact architecture), {B * S} x 30 s utterances per GPU per step"
                                    f"{'' if S == 1 else f' ({S} concurrent engine states x {B})'}, "
                                    f"greedy, no_timestamps, {args.tokens} forced tokens per utterance, PCM resident in HBM",
-                       "utterances_per_gpu": B * S, "engine_states_per_gpu": S, "pipeline_groups": args.pipeline_groups, "tokens_per_utterance": args.tokens, "enc_chunk": args.enc_chunk, "parallelism": f"dp{world} by utterance"},
+                       "utterances_per_gpu": B * S, "engine_states_per_gpu": S, "pipeline_groups": args.pipeline_groups, "encoder_lanes": args.encoder_lanes, "tokens_per_utterance": args.tokens, "enc_chunk": args.enc_chunk, "parallelism": f"dp{world} by utterance"},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (encoder conv/QKV/out/MLP/cross-KV GEMMs)", "achieved": achieved,
                          "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": f"bytes per launch at the L2-fabric boundary (HBM + Infinity Cache), mean over the class, from profiles/{traffic_src}" if traffic else None,

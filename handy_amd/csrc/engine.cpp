@@ -55,7 +55,7 @@ Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
     Tp_full_ = round_up(T_full_, 128);
     if (hipSetDevice(m->device) != hipSuccess) return;
     if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return;
-    if (hipStreamCreateWithFlags(&enc_stream_, hipStreamNonBlocking) != hipSuccess) return;
+    for (int l = 0; l < kEncLanes; l++) if (hipStreamCreateWithFlags(&enc_streams_[l], hipStreamNonBlocking) != hipSuccess) return;
     prof_stream_ = stream_;
     ok_ = alloc_workspaces();
 }
@@ -63,30 +63,37 @@ Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
 Engine::~Engine() {
     (void)hipSetDevice(model->device);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    if (enc_stream_) (void)hipStreamSynchronize(enc_stream_);
-    for (DevBuf *b : {&pcm_, &mel_raw_, &mel_max_, &mel_utt_dev_, &mel_norm_tmp_, &melT_, &h1_, &x_, &xn_, &q_, &k_, &vt_, &att_, &hid_, &enc16_, &enc32_,
+    for (int l = 0; l < kEncLanes; l++) {
+        if (enc_streams_[l]) (void)hipStreamSynchronize(enc_streams_[l]);
+        for (DevBuf *b : {&ews_[l].melT, &ews_[l].h1, &ews_[l].x, &ews_[l].xn, &ews_[l].q, &ews_[l].k, &ews_[l].vt, &ews_[l].att, &ews_[l].hid, &ews_[l].enc16}) b->release();
+    }
+    for (DevBuf *b : {&pcm_, &mel_raw_, &mel_max_, &mel_utt_dev_, &mel_norm_tmp_, &enc32_,
                       &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_, &sample_ws_, &splitk_ws_})
         b->release();
     meta_host_.release(); out_host_.release(); probs_host_.release(); win_host_.release(); slots_host_.release();
     for (hipEvent_t e : enc_events_) (void)hipEventDestroy(e);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (stream_) (void)hipStreamDestroy(stream_);
-    if (enc_stream_) (void)hipStreamDestroy(enc_stream_);
+    for (int l = 0; l < kEncLanes; l++) if (enc_streams_[l]) (void)hipStreamDestroy(enc_streams_[l]);
 }
 
 bool Engine::alloc_workspaces() {
     const int E = enc_chunk_, T = T_full_, d = d_;
     const size_t M1 = (size_t)E * (2 * T + 2), M2p = round_up(E * (T + 1), 256), Mp = round_up(E * T, 256);
     bool ok = true;
-    ok &= melT_.ensure(((M1 + 512) * n_mel_ + 1024) * sizeof(f16));
-    ok &= h1_.ensure(((std::max(M1 + 2, 2 * M2p + 8) + 256) * d) * sizeof(f16));
-    ok &= x_.ensure(Mp * d * sizeof(float));
-    ok &= xn_.ensure(Mp * d * sizeof(f16));
-    ok &= att_.ensure(Mp * d * sizeof(f16));
-    ok &= hid_.ensure(Mp * 4 * d * sizeof(f16));
-    ok &= enc16_.ensure(Mp * d * sizeof(f16));
     const size_t qkv = (size_t)E * H_ * Tp_full_ * 64 * sizeof(f16);
-    ok &= q_.ensure(qkv); ok &= k_.ensure(qkv); ok &= vt_.ensure(qkv);
+    const int lanes = 1;                                        // the second lane's workspace is allocated when it is switched on
+    for (int l = 0; l < lanes; l++) {
+        EncWs &w = ews_[l];
+        ok &= w.melT.ensure(((M1 + 512) * n_mel_ + 1024) * sizeof(f16));
+        ok &= w.h1.ensure(((std::max(M1 + 2, 2 * M2p + 8) + 256) * d) * sizeof(f16));
+        ok &= w.x.ensure(Mp * d * sizeof(float));
+        ok &= w.xn.ensure(Mp * d * sizeof(f16));
+        ok &= w.att.ensure(Mp * d * sizeof(f16));
+        ok &= w.hid.ensure(Mp * 4 * d * sizeof(f16));
+        ok &= w.enc16.ensure(Mp * d * sizeof(f16));
+        ok &= w.q.ensure(qkv); ok &= w.k.ensure(qkv); ok &= w.vt.ensure(qkv);
+    }
     ring_cap_ = 2 * max_utts_ + 4 * E;       // more than everything that can be queued at once, even after a wrap
     ok &= win_dev_.ensure(sizeof(WinDesc) * ring_cap_); ok &= slots_dev_.ensure(sizeof(int) * ring_cap_);
     ok &= win_host_.ensure(sizeof(WinDesc) * ring_cap_); ok &= slots_host_.ensure(sizeof(int) * ring_cap_);
@@ -116,6 +123,20 @@ bool Engine::alloc_workspaces() {
     logits_host_.assign(V_, 0.0f);
     ok &= ensure_rows(std::max(128, max_seqs));
     return ok;
+}
+
+bool Engine::set_encoder_lanes(int n) {
+    n = std::max(1, std::min(n, kEncLanes));
+    if (n > 1 && !ews_[1].x.p) {           // same sizes as lane 0
+        (void)hipSetDevice(model->device);
+        bool ok = true;
+        const EncWs &a = ews_[0]; EncWs &w = ews_[1];
+        ok &= w.melT.ensure(a.melT.cap); ok &= w.h1.ensure(a.h1.cap); ok &= w.x.ensure(a.x.cap); ok &= w.xn.ensure(a.xn.cap); ok &= w.att.ensure(a.att.cap);
+        ok &= w.hid.ensure(a.hid.cap); ok &= w.enc16.ensure(a.enc16.cap); ok &= w.q.ensure(a.q.cap); ok &= w.k.ensure(a.k.cap); ok &= w.vt.ensure(a.vt.cap);
+        if (!ok) return false;
+    }
+    encoder_lanes = n;
+    return true;
 }
 
 bool Engine::ensure_rows(int rows) {
@@ -153,7 +174,7 @@ void Engine::prof_end() {
 void Engine::collect_stats() {
     if (!ev_used_) return;
     (void)hipStreamSynchronize(stream_);
-    (void)hipStreamSynchronize(enc_stream_);
+    for (int l = 0; l < kEncLanes; l++) (void)hipStreamSynchronize(enc_streams_[l]);
     for (size_t i = 0; i < ev_used_; i++) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b) == hipSuccess) {
@@ -255,11 +276,12 @@ hipEvent_t Engine::next_enc_event() {
     return enc_events_[enc_events_used_++];
 }
 
-bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32, hipStream_t stream_) {
+bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32, hipStream_t stream_, int lane) {
     // (the parameter shadows the member on purpose: every launch below goes to the caller's stream)
     const int E = (int)wins.size(), d = d_, T2 = 2 * T, Tp = Tp_full_;
     if (E <= 0) return true;
-    if (E > enc_chunk_ || T <= 0 || T > T_full_) return false;
+    if (E > enc_chunk_ || T <= 0 || T > T_full_ || lane < 0 || lane >= kEncLanes || !ews_[lane].x.p) return false;
+    EncWs &w = ews_[lane];
     prof_stream_ = stream_;
     // chunk metadata goes through a pinned ring: the copy is asynchronous and a later chunk must not overwrite it
     if (ring_pos_ + E > ring_cap_) ring_pos_ = 0;
@@ -270,28 +292,28 @@ bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<in
     WMI_HIP_OK(hipMemcpyAsync(dw, hw, sizeof(WinDesc) * E, hipMemcpyHostToDevice, stream_));
     WMI_HIP_OK(hipMemcpyAsync(ds, hs, sizeof(int) * E, hipMemcpyHostToDevice, stream_));
     const double win_bytes = (double)E * T2 * n_mel_ * 6;
-    if (mel_user_) PROF(WMI_K_ENC_OTHER, win_bytes, mel_window_normalized(mel_raw_.as<float>(), dw, E, n_mel_, T2, melT_.as<f16>(), stream_));
-    else PROF(WMI_K_ENC_OTHER, win_bytes, mel_window(mel_raw_.as<float>(), mel_max_.as<unsigned>(), dw, E, n_mel_, T2, melT_.as<f16>(), stream_));
+    if (mel_user_) PROF(WMI_K_ENC_OTHER, win_bytes, mel_window_normalized(mel_raw_.as<float>(), dw, E, n_mel_, T2, w.melT.as<f16>(), stream_));
+    else PROF(WMI_K_ENC_OTHER, win_bytes, mel_window(mel_raw_.as<float>(), mel_max_.as<unsigned>(), dw, E, n_mel_, T2, w.melT.as<f16>(), stream_));
     const int M1 = E * (T2 + 2), M2 = E * (T + 1), M = E * T;
     const int K1 = 3 * n_mel_;
-    PROF(WMI_K_ENC_GEMM, 2.0 * E * T2 * d * K1, gemm_conv1(melT_.as<f16>(), n_mel_, model->conv1_w, model->conv1_kpad, M1, d, h1_.as<f16>(), model->conv1_b, T2, stream_));
-    PROF(WMI_K_ENC_GEMM, 2.0 * M * d * 3 * d, gemm_conv2(h1_.as<f16>(), model->conv2_w, M2, d, x_.as<float>(), model->conv2_b, model->e_pe, T, stream_));
+    PROF(WMI_K_ENC_GEMM, 2.0 * E * T2 * d * K1, gemm_conv1(w.melT.as<f16>(), n_mel_, model->conv1_w, model->conv1_kpad, M1, d, w.h1.as<f16>(), model->conv1_b, T2, stream_));
+    PROF(WMI_K_ENC_GEMM, 2.0 * M * d * 3 * d, gemm_conv2(w.h1.as<f16>(), model->conv2_w, M2, d, w.x.as<float>(), model->conv2_b, model->e_pe, T, stream_));
     const double ln_bytes = (double)M * d * 6;
     for (int l = 0; l < Le_; l++) {
         const EncLayer &L = model->enc[l];
-        PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(x_.as<float>(), L.ln1_w, L.ln1_b, xn_.as<f16>(), nullptr, M, d, nullptr, stream_));
-        PROF(WMI_K_ENC_GEMM, 2.0 * M * 3 * d * d, gemm_enc_qkv(xn_.as<f16>(), L.wqkv, M, d, H_, T, Tp, q_.as<f16>(), k_.as<f16>(), vt_.as<f16>(), L.bqkv, stream_));
-        PROF(WMI_K_ENC_ATTN, 4.0 * E * (double)T * T * d, enc_attention(q_.as<f16>(), k_.as<f16>(), vt_.as<f16>(), att_.as<f16>(), E, H_, T, Tp, stream_));
-        PROF(WMI_K_ENC_GEMM, 2.0 * M * d * d, gemm_residual(att_.as<f16>(), d, L.wo, d, M, d, d, x_.as<float>(), d, L.bo, stream_));
-        PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(x_.as<float>(), L.ln2_w, L.ln2_b, xn_.as<f16>(), nullptr, M, d, nullptr, stream_));
-        PROF(WMI_K_ENC_GEMM, 2.0 * M * 4 * d * d, gemm_f16(xn_.as<f16>(), d, L.fc1, d, M, 4 * d, d, hid_.as<f16>(), 4 * d, L.b1, 1, 1.0f, stream_));
-        PROF(WMI_K_ENC_GEMM, 2.0 * M * 4 * d * d, gemm_residual(hid_.as<f16>(), 4 * d, L.fc2, 4 * d, M, d, 4 * d, x_.as<float>(), d, L.b2, stream_));
+        PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(w.x.as<float>(), L.ln1_w, L.ln1_b, w.xn.as<f16>(), nullptr, M, d, nullptr, stream_));
+        PROF(WMI_K_ENC_GEMM, 2.0 * M * 3 * d * d, gemm_enc_qkv(w.xn.as<f16>(), L.wqkv, M, d, H_, T, Tp, w.q.as<f16>(), w.k.as<f16>(), w.vt.as<f16>(), L.bqkv, stream_));
+        PROF(WMI_K_ENC_ATTN, 4.0 * E * (double)T * T * d, enc_attention(w.q.as<f16>(), w.k.as<f16>(), w.vt.as<f16>(), w.att.as<f16>(), E, H_, T, Tp, stream_));
+        PROF(WMI_K_ENC_GEMM, 2.0 * M * d * d, gemm_residual(w.att.as<f16>(), d, L.wo, d, M, d, d, w.x.as<float>(), d, L.bo, stream_));
+        PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(w.x.as<float>(), L.ln2_w, L.ln2_b, w.xn.as<f16>(), nullptr, M, d, nullptr, stream_));
+        PROF(WMI_K_ENC_GEMM, 2.0 * M * 4 * d * d, gemm_f16(w.xn.as<f16>(), d, L.fc1, d, M, 4 * d, d, w.hid.as<f16>(), 4 * d, L.b1, 1, 1.0f, stream_));
+        PROF(WMI_K_ENC_GEMM, 2.0 * M * 4 * d * d, gemm_residual(w.hid.as<f16>(), 4 * d, L.fc2, 4 * d, M, d, 4 * d, w.x.as<float>(), d, L.b2, stream_));
     }
     float *e32 = nullptr;
     if (want_f32) { if (!enc32_.ensure((size_t)round_up(M, 256) * d * sizeof(float))) return false; e32 = enc32_.as<float>(); }
-    PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(x_.as<float>(), model->ln_post_w, model->ln_post_b, enc16_.as<f16>(), e32, M, d, nullptr, stream_));
+    PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(w.x.as<float>(), model->ln_post_w, model->ln_post_b, w.enc16.as<f16>(), e32, M, d, nullptr, stream_));
     PROF(WMI_K_ENC_GEMM, 2.0 * M * (2.0 * Ld_ * d) * d,
-         gemm_cross_kv(enc16_.as<f16>(), model->xkv_w, M, d, H_, T, Tp, Ld_, ckv_.as<f16>(), model->xkv_b, ds, stream_));
+         gemm_cross_kv(w.enc16.as<f16>(), model->xkv_w, M, d, H_, T, Tp, Ld_, ckv_.as<f16>(), model->xkv_b, ds, stream_));
     prof_stream_ = this->stream_;
     enc_T_ = T;
     n_encode += E;
@@ -305,7 +327,7 @@ int Engine::encode(int offset, int audio_ctx) {
     if (T > T_full_) return -1;
     const double t0 = now_ms();
     WinDesc w{mel_utt_[0].mel_off, mel_utt_[0].n_frames, utt_n_len_[0], offset, 0};
-    if (!encode_chunk({w}, {0}, T, true, stream_)) return -1;
+    if (!encode_chunk({w}, {0}, T, true, stream_, 0)) return -1;
     if (hipStreamSynchronize(stream_) != hipSuccess) return -1;
     t_encode_ms += now_ms() - t0;
     return 0;
@@ -893,9 +915,10 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
                 }
                 if (wins.empty()) continue;
                 // language detection always uses the full audio context
-                if (!E.encode_chunk(wins, slots, T, false, E.enc_stream_)) { rc = -6; break; }
+                const int lane = (E.encoder_lanes > 1 && E.ews_[1].x.p) ? (E.next_lane_++ & 1) : 0;
+                if (!E.encode_chunk(wins, slots, T, false, E.enc_streams_[lane], lane)) { rc = -6; break; }
                 hipEvent_t ev = E.next_enc_event();
-                if (!ev || hipEventRecord(ev, E.enc_stream_) != hipSuccess) { rc = -6; break; }
+                if (!ev || hipEventRecord(ev, E.enc_streams_[lane]) != hipSuccess) { rc = -6; break; }
                 for (int i : members) utts[i].enc_ev = ev;
             }
             if (rc) break;
@@ -910,6 +933,15 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
         //      The batch is cut into E.pipeline_groups index ranges; a group decodes once every earlier group is finished,
         //      so decoder passes stay full (a pass costs nearly the same for 16 rows as for 64: it streams all the weights)
         //      while the encoder is still busy with the later groups.
+        if (E.pipeline_groups <= 1) {              // no overlap: everything queued on the encoder lanes finishes first
+            bool pending = false;
+            for (int i = 0; i < G; i++) pending |= utts[i].enc_ev != nullptr;
+            if (pending) {
+                for (int l = 0; l < kEncLanes; l++) if (hipStreamSynchronize(E.enc_streams_[l]) != hipSuccess) rc = -6;
+                if (rc) break;
+                for (int i = 0; i < G; i++) utts[i].enc_ev = nullptr;
+            }
+        }
         const int n_groups = std::max(1, std::min(E.pipeline_groups, G));
         int open_group = n_groups;
         for (int i = 0; i < G; i++) if (utts[i].phase != Phase::Done) { open_group = (int)((long)i * n_groups / G); break; }
@@ -1019,7 +1051,7 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
             }
         }
     }
-    if (rc) (void)hipStreamSynchronize(E.enc_stream_);        // an early exit must not leave encoder work behind the caller's back
+    if (rc) for (int l = 0; l < kEncLanes; l++) (void)hipStreamSynchronize(E.enc_streams_[l]);        // an early exit must not leave encoder work behind the caller's back
     for (Utt &u : utts) { release_decoders(u); if (u.rc != 0) { E.results[u.index].rc = u.rc; if (!rc) rc = u.rc; } }
     return rc;
 }

@@ -104,6 +104,8 @@ public:
     std::vector<UttResult> results;
     int force_tokens = 0;
     int pipeline_groups = 1;             // index ranges of a batch that decode one after the other while later ones still encode
+    int encoder_lanes = 1;               // 2: alternate encoder chunks between two streams/workspaces
+    bool set_encoder_lanes(int n);
     bool beam_sampled = false;
     int exp_n_audio_ctx = 0;
 
@@ -121,7 +123,6 @@ private:
     bool ok_ = false;
     int max_utts_, max_dec_, enc_chunk_;
     hipStream_t stream_ = nullptr;       // decoder passes, log-mel, the low-level whisper_encode/decode calls
-    hipStream_t enc_stream_ = nullptr;   // encoder chunks of whisper_full: they run beside the decoder passes of earlier chunks
     hipStream_t prof_stream_ = nullptr;  // where the profiling events of the kernels being launched go
     int d_, H_, Le_, Ld_, T_full_, n_mel_, V_, Vp_;
 
@@ -132,7 +133,14 @@ private:
     bool mel_user_ = false;          // whisper_set_mel: mel_raw_ holds an already normalised mel
 
     // encoder workspace
-    DevBuf melT_, h1_, x_, xn_, q_, k_, vt_, att_, hid_, enc16_, enc32_, win_dev_, slots_dev_;
+    // Two encoder lanes (stream + workspace set): whisper_full alternates chunks between them, so while one chunk's
+    // kernel drains (last partial round of tiles, launch gap) the other chunk's kernel already fills the idle CUs.
+    struct EncWs { DevBuf melT, h1, x, xn, q, k, vt, att, hid, enc16; };
+    static constexpr int kEncLanes = 2;
+    EncWs ews_[kEncLanes];
+    hipStream_t enc_streams_[kEncLanes] = {nullptr, nullptr};
+    int next_lane_ = 0;
+    DevBuf enc32_, win_dev_, slots_dev_;
     PinnedBuf win_host_, slots_host_;    // per-chunk metadata: a ring, so that several chunks can be queued before the first one runs
     int ring_pos_ = 0, ring_cap_ = 0;
     std::vector<hipEvent_t> enc_events_; // pool of encoder-chunk completion events
@@ -165,7 +173,7 @@ private:
     bool alloc_workspaces();
     bool ensure_rows(int rows);
     bool compute_mel(const float *pcm_dev_base, const std::vector<long> &offs, const std::vector<int> &n);
-    bool encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32, hipStream_t s);
+    bool encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32, hipStream_t s, int lane);
     struct PassOut { std::vector<SampleOut> so; std::vector<TopkOut> topk; };
     bool decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow> &srows, const std::vector<const Decoder *> &seqs,
                       const std::vector<int2> &page_copies, int T, bool want_raw_logits_host, float *logits_all_out);

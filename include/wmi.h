@@ -47,6 +47,10 @@ WHISPER_API void wmi_set_force_tokens(struct whisper_state *state, int n);
  * while the encoder (MFMA-bound) is still working on ranges k+1.. on a second stream. 1 = encode everything first. Results do
  * not depend on n. */
 WHISPER_API void wmi_set_pipeline_groups(struct whisper_state *state, int n);
+/* 2: alternate the encoder chunks of a batch between two streams with their own workspaces (a second ~0.9 GB set for
+ * large-v3-turbo at 16 utterances per chunk), so one chunk's kernels fill the CUs another chunk's draining kernels leave idle.
+ * Per-kernel event times then overlap; leave it at 1 when measuring single kernels. Returns 0, or -1 when out of memory. */
+WHISPER_API int wmi_set_encoder_lanes(struct whisper_state *state, int n);
 /* Beam-search candidate rule: 0 = deterministic k most probable tokens per beam (default),
  * 1 = k draws from the token distribution with a per-decoder mt19937 (what upstream does). */
 WHISPER_API void wmi_set_beam_candidates_sampled(struct whisper_state *state, int sampled);
