@@ -144,7 +144,7 @@ bool Engine::ensure_rows(int rows) {
     const size_t R = round_up(rows, 256);
     bool ok = dx_.ensure(R * d_ * sizeof(float)) && dxn_.ensure(R * d_ * sizeof(f16)) && dq_.ensure(R * d_ * sizeof(f16)) &&
               datt_.ensure(R * d_ * sizeof(f16)) && dhid_.ensure(R * 4 * d_ * sizeof(f16));
-    const size_t meta = R * sizeof(DecRow) + (size_t)lrows_cap_ * (sizeof(SampleRow) + sizeof(int) * (kMaxPagesPerSeq + 1)) + R * sizeof(int2) + 4096;
+    const size_t meta = R * sizeof(DecRow) + (size_t)lrows_cap_ * (sizeof(SampleRow) + sizeof(int) * (kMaxPagesPerSeq + 1)) + 2 * R * sizeof(int2) + 4096;
     ok = ok && meta_dev_.ensure(meta) && meta_host_.ensure(meta);
     ok = ok && splitk_ws_.ensure(gemm_splitk_workspace_bytes((int)std::min<size_t>(R, kSplitMaxRows), d_), false);
     if (ok) rows_cap_ = (int)R;
@@ -391,8 +391,19 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     if (!ensure_rows(std::max(R, C))) return false;
     // one packed metadata upload
     char *hb = meta_host_.as<char>();
+    // runs of consecutive rows of one utterance (beams, prompt tokens), cut at 8: they share one sweep over the cross K/V
+    xgroups_.clear();
+    int max_group = 1;
+    for (int r = 0; r < R;) {
+        int e = r + 1;
+        while (e < R && e - r < 8 && rows[e].utt == rows[r].utt) e++;
+        xgroups_.push_back(int2{r, e - r});
+        max_group = std::max(max_group, e - r);
+        r = e;
+    }
+    const int NG = (int)xgroups_.size();
     size_t o_rows = 0, o_srow = o_rows + sizeof(DecRow) * R, o_bt = o_srow + sizeof(SampleRow) * L, o_gather = o_bt + sizeof(int) * kMaxPagesPerSeq * S,
-           o_copy = round_up_sz(o_gather + sizeof(int) * L, 8), total = o_copy + sizeof(int2) * C;
+           o_copy = round_up_sz(o_gather + sizeof(int) * L, 8), o_grp = o_copy + sizeof(int2) * C, total = o_grp + sizeof(int2) * NG;
     if (total > meta_host_.cap) return false;
     memcpy(hb + o_rows, rows.data(), sizeof(DecRow) * R);
     if (L) memcpy(hb + o_srow, srows.data(), sizeof(SampleRow) * L);
@@ -401,12 +412,14 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     int *gather = (int *)(hb + o_gather);
     for (int r = 0; r < R; r++) if (rows[r].logit_row >= 0) gather[rows[r].logit_row] = r;
     if (C) memcpy(hb + o_copy, page_copies.data(), sizeof(int2) * C);
+    if (max_group > 1) memcpy(hb + o_grp, xgroups_.data(), sizeof(int2) * NG);
     WMI_HIP_OK(hipMemcpyAsync(meta_dev_.p, hb, total, hipMemcpyHostToDevice, stream_));
     char *db = meta_dev_.as<char>();
     const DecRow *d_rows = (const DecRow *)(db + o_rows);
     const SampleRow *d_srow = (const SampleRow *)(db + o_srow);
     const int *d_bt = (const int *)(db + o_bt), *d_gather = (const int *)(db + o_gather);
     const int2 *d_copy = (const int2 *)(db + o_copy);
+    const int2 *d_grp = max_group > 1 ? (const int2 *)(db + o_grp) : nullptr;
     f16 *kp = kpool_.as<f16>(), *vp = vpool_.as<f16>();
     if (C) PROF(WMI_K_DEC_OTHER, 0, copy_pages(kp, vp, layer_stride_, Ld_, d_copy, C, H_, stream_));
     PROF(WMI_K_DEC_OTHER, (double)R * d * 6, dec_embed(model->d_te, model->d_pe, d_rows, R, d, dx_.as<float>(), stream_));
@@ -447,7 +460,7 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         } else {
             PROF(WMI_K_DEC_GEMM, w1, gemm_f16(dxn_.as<f16>(), d, D.xq, d, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_));
         }
-        PROF(WMI_K_DEC_CROSS_ATTN, (double)R * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
+        PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp, NG, max_group, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
         if (fused_ln) { if (!residual_ln(datt_.as<f16>(), d, D.xo, D.bxo, s_dd, D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R)) return false; }
         else {
             PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.xo, d, R, d, d, dx_.as<float>(), d, D.bxo, stream_));

@@ -161,6 +161,7 @@ private:
     PinnedBuf meta_host_, out_host_, probs_host_;
     std::vector<float> logits_host_;
     Decoder ll_dec_;                 // sequence used by whisper_decode()
+    std::vector<int2> xgroups_;      // cross-attention row groups of the pass being built
 
     // event pool for profiling
     struct EvPair { hipEvent_t a, b; int cls; double work; };

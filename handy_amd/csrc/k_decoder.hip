@@ -118,31 +118,55 @@ bool dec_self_attention(const f16 *q, const f16 *kc, const f16 *vc, const int *b
 }
 
 // Cross-attention: T (1500) keys per (row, head), 384 KB of K+V streamed per pair; 4 waves = 32 keys per pass.
+// Rows that belong to one utterance (the beams of a beam search, the tokens of a prompt) read the same K and V:
+// a workgroup takes a group of up to NQ such rows (consecutive in the pass; the host passes {first row, count})
+// and applies every key it loads to all of them, so the cache is streamed once per group, not once per row.
+template <int NQ>
 __global__ __launch_bounds__(256) void dec_cross_attention_kernel(const f16 *__restrict__ qb, const f16 *__restrict__ ckv, const DecRow *__restrict__ rows,
-                                                                  int d, int H, int T, int Tp, int n_layer, int layer, f16 *__restrict__ att) {
+                                                                  const int2 *__restrict__ groups, int d, int H, int T, int Tp, int n_layer, int layer, f16 *__restrict__ att) {
     __shared__ float red[4][8][10];
-    const int head = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 3, e8 = lane & 7;
-    const long slot = rows[m].utt;
+    const int head = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 3, e8 = lane & 7;
+    const int m0 = NQ == 1 ? (int)blockIdx.y : groups[blockIdx.y].x, cnt = NQ == 1 ? 1 : groups[blockIdx.y].y;
+    const long slot = rows[m0].utt;
     const f16 *kp = ckv + ((((slot * n_layer + layer) * 2 + 0) * H + head) * (long)Tp) * 64 + e8 * 8;
     const f16 *vp = kp + (long)H * Tp * 64;
-    float q[8];
-    { const f16x8 qv = *(const f16x8 *)(qb + (long)m * d + head * 64 + e8 * 8);
+    float q[NQ][8];
+    AttnAcc s[NQ];
 #pragma unroll
-      for (int i = 0; i < 8; i++) q[i] = (float)qv[i]; }
-    AttnAcc s; attn_init(s);
+    for (int c = 0; c < NQ; c++) {
+        const f16x8 qv = *(const f16x8 *)(qb + (long)(m0 + (c < cnt ? c : 0)) * d + head * 64 + e8 * 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[c][i] = (float)qv[i];
+        attn_init(s[c]);
+    }
     int j = wave * 8 + g;
     for (; j + 32 < T; j += 64) {          // two independent key rows in flight per iteration
         const f16x8 k0 = *(const f16x8 *)(kp + (long)j * 64), v0 = *(const f16x8 *)(vp + (long)j * 64);
         const f16x8 k1 = *(const f16x8 *)(kp + (long)(j + 32) * 64), v1 = *(const f16x8 *)(vp + (long)(j + 32) * 64);
-        attn_step(s, q, k0, v0);
-        attn_step(s, q, k1, v1);
+#pragma unroll
+        for (int c = 0; c < NQ; c++) { attn_step(s[c], q[c], k0, v0); attn_step(s[c], q[c], k1, v1); }
     }
-    for (; j < T; j += 32) attn_step(s, q, *(const f16x8 *)(kp + (long)j * 64), *(const f16x8 *)(vp + (long)j * 64));
-    attn_block_finish(s, red, tid, att + (long)m * d + head * 64);
+    for (; j < T; j += 32) {
+        const f16x8 k0 = *(const f16x8 *)(kp + (long)j * 64), v0 = *(const f16x8 *)(vp + (long)j * 64);
+#pragma unroll
+        for (int c = 0; c < NQ; c++) attn_step(s[c], q[c], k0, v0);
+    }
+#pragma unroll
+    for (int c = 0; c < NQ; c++) {
+        if (c < cnt) attn_block_finish(s[c], red, tid, att + (long)(m0 + c) * d + head * 64);      // cnt is uniform over the workgroup
+        if (NQ > 1) __syncthreads();                                                                // red is reused by the next row
+    }
 }
-bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, int M, int d, int H, int T, int Tp, int n_layer, int layer, f16 *att, hipStream_t st) {
+bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, const int2 *groups, int n_groups, int max_group, int M, int d, int H, int T, int Tp,
+                         int n_layer, int layer, f16 *att, hipStream_t st) {
     if (M <= 0) return true;
-    hipLaunchKernelGGL(dec_cross_attention_kernel, dim3(H, M), dim3(256), 0, st, q, ckv, rows, d, H, T, Tp, n_layer, layer, att);
+#define WMI_XATT(NQ_) hipLaunchKernelGGL((dec_cross_attention_kernel<NQ_>), dim3(H, NQ_ == 1 ? M : n_groups), dim3(256), 0, st, q, ckv, rows, groups, d, H, T, Tp, n_layer, layer, att)
+    if (max_group <= 1 || !groups) WMI_XATT(1);
+    else if (max_group <= 2) WMI_XATT(2);
+    else if (max_group <= 4) WMI_XATT(4);
+    else if (max_group <= 8) WMI_XATT(8);
+    else return false;
+#undef WMI_XATT
     return hipGetLastError() == hipSuccess;
 }
 

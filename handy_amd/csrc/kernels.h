@@ -60,7 +60,9 @@ bool dec_embed(const f16 *te, const float *pe, const DecRow *rows, int M, int d,
 // causal self-attention over the paged cache: kc/vc [page][H][16][64], block_table [seq][kMaxPagesPerSeq]
 bool dec_self_attention(const f16 *q, const f16 *kc, const f16 *vc, const int *block_table, const DecRow *rows, int M, int d, int H, f16 *att, hipStream_t st);
 // cross-attention over cached encoder K/V: ckv [slot][layer][2][H][Tp][64]
-bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, int M, int d, int H, int T, int Tp, int n_layer, int layer, f16 *att, hipStream_t st);
+// groups: {first row, count <= max_group <= 8} runs of consecutive rows of one utterance (nullptr / max_group 1: one row per workgroup)
+bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, const int2 *groups, int n_groups, int max_group, int M, int d, int H, int T, int Tp,
+                         int n_layer, int layer, f16 *att, hipStream_t st);
 // logits rules + log-softmax + argmax / top-k / probabilities for every logit row
 // (the masked logits are written back in place; nst_bitmap has one bit per token id)
 // any_extra: some row has topk > 0 or want_probs; workspace: sample_workspace_bytes(max rows) of device memory
