@@ -148,6 +148,44 @@ def test_batch_equals_single_and_ragged_inputs(wr, model_path):
     bst.free(); st.free(); ctx.free()
 
 
+VARIANTS = {
+    "audio_ctx": lambda fp: fp.set_audio_ctx(768),
+    "translate": lambda fp: fp.set_translate(True),
+    "single_segment": lambda fp: fp.set_single_segment(True),
+    "max_tokens": lambda fp: fp.set_max_tokens(20),
+    "offset_duration": lambda fp: (fp.set_offset_ms(5000), fp.set_duration_ms(12000)),
+    "prompt_tokens": lambda fp: fp.set_tokens([1001, 2002, 3003, 404, 505]),
+    "print_special": lambda fp: fp.set_print_special(True),
+    "no_blank_rule_nst_rule": lambda fp: (fp.set_suppress_blank(False), fp.set_suppress_nst(True)),
+    "max_initial_ts": lambda fp: fp.set_max_initial_ts(0.5),
+    "tdrz": lambda fp: fp.set_tdrz_enable(True),
+    "no_timestamps": lambda fp: fp.set_no_timestamps(True),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_full_params_variants_match_oracle(wr, oracle, model_path, variant):
+    """One whisper_full parameter changed at a time (the ones transcribe-rs / whisper-rs callers can reach), greedy,
+    multilingual model, against the oracle: identical tokens, timestamps and text."""
+    path = model_path("micro", decisive=4.0)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0)
+    fp.set_language("de")
+    VARIANTS[variant](fp)
+    pcms = [synth_pcm(300 + i, int(16000 * s)) for i, s in enumerate((30.0, 17.0, 41.0))]
+    okw = {}
+    if variant == "prompt_tokens":
+        arr = (C.c_int32 * 5)(1001, 2002, 3003, 404, 505)
+        okw = {"prompt_tokens": C.cast(arr, C.POINTER(C.c_int32)), "prompt_n_tokens": 5, "_keep": arr}
+    keep = okw.pop("_keep", None)
+    got, ref, _ = _run_pair(wr, oracle, path, fp, pcms, **okw)
+    same = [_same(g, r) for g, r in zip(got, ref)]
+    print(variant, same, [sum(len(s["tokens"]) for s in r) for r in ref])
+    assert all(same)
+    assert sum(len(s["tokens"]) for r in ref for s in r) > 10
+    del keep
+
+
 def test_pipeline_groups_do_not_change_results(wr, model_path):
     """Decoding index ranges of the batch one after the other while the encoder stream still works on the later ones
     (wmi_set_pipeline_groups) changes which sequences share a decoder pass, never their tokens."""
