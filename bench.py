@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--pipeline-groups", type=int, default=int(os.environ.get("WMI_PIPELINE_GROUPS", "1")),
                     help="index ranges of the batch that decode one after the other while the encoder works on the later ones")
     ap.add_argument("--encoder-lanes", type=int, default=int(os.environ.get("WMI_ENCODER_LANES", "1")), help="2: alternate encoder chunks between two streams")
+    ap.add_argument("--dist-backend", default=os.environ.get("WMI_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend of the result gather; 'gloo' together with --all-ranks-on-device0 rehearses the multi-rank path on one GPU")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed step that profiles every kernel class")
     args = ap.parse_args()
@@ -123,11 +126,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.all_ranks_on_device0 else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
+    gather_dev = dev if args.dist_backend == "nccl" else None
 
     from handy_amd import whisper_rs as wr
     from handy_amd.synth import synth_pcm
@@ -139,7 +147,7 @@ def main():
         dist.barrier()
     path = model_file(args.arch)
 
-    ctx = wr.WhisperContext(path, wr.WhisperContextParameters(local_rank))
+    ctx = wr.WhisperContext(path, wr.WhisperContextParameters(dev_index))
     B = args.batch
     S = max(1, args.streams)
     states = [ctx.create_batch_state(B, 1, args.enc_chunk) for _ in range(S)]
@@ -165,7 +173,7 @@ def main():
 
     import threading
 
-    def step():
+    def step(gather=True):
         # S engine states run the same hot path concurrently (own stream, own host thread; ctypes drops the GIL during
         # the call): while one state's decoder streams K/V and weights from HBM, another state's encoder keeps the MFMAs busy
         if S == 1:
@@ -185,8 +193,8 @@ def main():
         recs = [pack_token_records(range((rank * S + k) * B, (rank * S + k + 1) * B), [s_.batch_tokens(u) for u in range(B)], args.tokens + 2)
                 for k, s_ in enumerate(states)]
         rec = np.concatenate(recs, axis=0)
-        if world > 1:       # the only collective on the path: gather the per-utterance token records on rank 0 (RCCL)
-            gather_token_records(rec, B * S, device=dev)
+        if world > 1 and gather:       # the only collective on the path: gather the per-utterance token records on rank 0 (RCCL)
+            gather_token_records(rec, B * S, device=gather_dev)
         return rec[:, 2:]
 
     for _ in range(args.warmup):
@@ -212,7 +220,7 @@ def main():
         st.set_profiling(True)
         st.reset_kernel_stats()
         t1 = time.perf_counter()
-        step()
+        step(gather=False)          # rank 0 alone: no collective here
         torch.cuda.synchronize()
         bd_ms = (time.perf_counter() - t1) * 1e3
         breakdown = st.kernel_stats()
@@ -221,7 +229,7 @@ def main():
     assert n_tok == args.tokens + 1, f"decode produced {n_tok} tokens per utterance, expected {args.tokens + 1}"
 
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if gather_dev is not None else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:

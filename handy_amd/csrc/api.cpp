@@ -364,6 +364,11 @@ int wmi_get_cross_kv(struct whisper_state *s, int layer, float *k, float *v) {
     Engine *e = ENG(s); return e && k && v ? e->get_cross_kv(layer, k, v) : -1;
     WMI_CATCH(-1)
 }
+int wmi_get_host_timings(struct whisper_state *s, double *out) {
+    Engine *e = ENG(s); if (!e || !out) return -1;
+    out[0] = e->t_mel_ms; out[1] = e->t_encode_ms; out[2] = e->t_decode_ms; out[3] = e->t_dec_launch_ms; out[4] = e->t_dec_wait_ms; out[5] = (double)e->n_passes;
+    return 0;
+}
 int wmi_set_encoder_lanes(struct whisper_state *s, int n) { Engine *e = ENG(s); try { return e && e->set_encoder_lanes(n) ? 0 : -1; } catch (...) { return -1; } }
 void wmi_set_pipeline_groups(struct whisper_state *s, int n) { if (Engine *e = ENG(s)) e->pipeline_groups = n < 1 ? 1 : n; }
 void wmi_set_profiling(struct whisper_state *s, int on) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = on != 0; e->profile_mask = ~0u; } }

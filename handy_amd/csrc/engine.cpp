@@ -387,6 +387,7 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
                           const std::vector<int2> &page_copies, int T, bool want_raw_logits_host, float *logits_all_out) {
     const int R = (int)rows.size(), L = (int)srows.size(), S = (int)seqs.size(), C = (int)page_copies.size(), d = d_;
     if (R <= 0) return true;
+    const double t_pass0 = now_ms();
     if (L > lrows_cap_ || S > lrows_cap_) { log_msg(2, "engine: decoder pass exceeds the state's capacity (%d logit rows)\n", L); return false; }
     if (!ensure_rows(std::max(R, C))) return false;
     // one packed metadata upload
@@ -496,7 +497,9 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         WMI_HIP_OK(hipMemcpyAsync(out_host_.p, out_dev_.p, sizeof(SampleOut) * lrows_cap_ + sizeof(TopkOut) * 8 * (size_t)L, hipMemcpyDeviceToHost, stream_));
         if (any_probs) WMI_HIP_OK(hipMemcpyAsync(probs_host_.p, probs_.p, sizeof(float) * (size_t)L * V_, hipMemcpyDeviceToHost, stream_));
     }
+    const double t_launched = now_ms();
     WMI_HIP_OK(hipStreamSynchronize(stream_));
+    t_dec_launch_ms += t_launched - t_pass0; t_dec_wait_ms += now_ms() - t_launched; n_passes++;
     n_decode += R;
     return true;
 }

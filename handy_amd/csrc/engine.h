@@ -118,6 +118,8 @@ public:
     // timings (ms, host clock around synchronised phases)
     double t_mel_ms = 0, t_encode_ms = 0, t_decode_ms = 0, t_load_ms = 0;
     int n_encode = 0, n_decode = 0;
+    double t_dec_launch_ms = 0, t_dec_wait_ms = 0;   // decoder passes: host time building + launching, then waiting for the stream
+    long n_passes = 0;
 
 private:
     bool ok_ = false;

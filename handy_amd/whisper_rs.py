@@ -117,7 +117,7 @@ whisper_full_get_token_data whisper_full_get_token_data_from_state whisper_full_
 wmi_init_state_batch wmi_full_batch wmi_batch_n_utts wmi_batch_n_segments wmi_batch_segment_t0 wmi_batch_segment_t1
 wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks
 wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
-wmi_decode_logits_all wmi_debug_gemm wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_version
+wmi_decode_logits_all wmi_debug_gemm wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_version
 """.split()
 
 _lib = None
@@ -195,6 +195,7 @@ def load_library(path: Optional[str] = None):
     L.wmi_set_profiling_classes.argtypes = [vp, C.c_uint]
     L.wmi_get_kernel_stats.restype = ci; L.wmi_get_kernel_stats.argtypes = [vp, C.POINTER(wmi_kernel_stat)]
     L.wmi_reset_kernel_stats.argtypes = [vp]
+    L.wmi_get_host_timings.restype = ci; L.wmi_get_host_timings.argtypes = [vp, C.POINTER(C.c_double)]
     if path is None:
         _lib = L
     return L
@@ -491,6 +492,10 @@ class WhisperState:
         for n in names: mask |= 1 << KERNEL_CLASSES.index(n)
         self.L.wmi_set_profiling_classes(self.h, mask)
     def reset_kernel_stats(self): self.L.wmi_reset_kernel_stats(self.h)
+    def host_timings(self):
+        a = (C.c_double * 6)()
+        self.L.wmi_get_host_timings(self.h, a)
+        return dict(zip(("mel_ms", "encode_launch_ms", "decode_ms", "decode_launch_ms", "decode_wait_ms", "passes"), list(a)))
 
     def kernel_stats(self):
         arr = (wmi_kernel_stat * len(KERNEL_CLASSES))()

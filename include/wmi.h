@@ -80,6 +80,10 @@ WHISPER_API void wmi_set_profiling_classes(struct whisper_state *state, unsigned
 WHISPER_API int wmi_get_kernel_stats(struct whisper_state *state, wmi_kernel_stat *out /* [WMI_K_COUNT] */);
 WHISPER_API void wmi_reset_kernel_stats(struct whisper_state *state);
 
+/* Host-side clocks accumulated by the state, ms: [0] log-mel phase, [1] encoder launches, [2] decoder passes,
+ * [3] of which building + launching, [4] of which waiting for the stream; [5] number of decoder passes. */
+WHISPER_API int wmi_get_host_timings(struct whisper_state *state, double *out /* [6] */);
+
 WHISPER_API const char *wmi_version(void);
 
 #ifdef __cplusplus

@@ -14,7 +14,8 @@ from handy_amd.synth import synth_pcm
 which = sys.argv[1:] or ["tiny", "small", "beam"]
 dev = torch.device("cuda", 0)
 n = 480000
-CFG = {"tiny": ("tiny.en", 1, 64, "greedy"), "small": ("small", 32, 128, "greedy"), "beam": ("large-v3", 64, 64, "beam5")}
+CFG = {"turbo1": ("large-v3-turbo", 1, 64, "greedy"), "turbo1beam": ("large-v3-turbo", 1, 64, "beam5"),
+       "tiny": ("tiny.en", 1, 64, "greedy"), "small": ("small", 32, 128, "greedy"), "beam": ("large-v3", 64, 64, "beam5")}
 for name in which:
     arch, B, tokens, mode = CFG[name]
     t0 = time.time(); path = model_file(arch); t_model = time.time() - t0
@@ -29,16 +30,22 @@ for name in which:
     ptrs = [pcm.data_ptr() + i * n * 4 for i in range(B)]; ns = [n] * B
     st.full_batch_device(fp, ptrs, ns)
     torch.cuda.synchronize()
-    st.set_profiling(True); st.reset_kernel_stats()
     steps = 3
     t0 = time.perf_counter()
     for _ in range(steps):
         st.full_batch_device(fp, ptrs, ns)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / steps              # timed without per-kernel events
+    ht = st.host_timings()
+    st.set_profiling(True); st.reset_kernel_stats()
+    for _ in range(steps):
+        st.full_batch_device(fp, ptrs, ns)
+    torch.cuda.synchronize()
     ks = st.kernel_stats()
+    st.set_profiling(False)
     n_tok = len(st.batch_tokens(0))
     print(json.dumps({"workload": name, "arch": arch, "utterances": B, "mode": mode, "tokens_per_utterance": n_tok, "ms_per_step": dt * 1e3, "rtfx": 30.0 * B / dt,
                       "kernel_classes_ms_per_step": {k: round(v["ms"] / steps, 2) for k, v in ks.items()},
-                      "cross_attn_TBps": ks["dec_cross_attn"]["work"] / max(ks["dec_cross_attn"]["ms"], 1e-9) / 1e9, "model_file_s": round(t_model, 1)}), flush=True)
+                      "cross_attn_TBps": ks["dec_cross_attn"]["work"] / max(ks["dec_cross_attn"]["ms"], 1e-9) / 1e9, "model_file_s": round(t_model, 1),
+                      "host_ms_per_pass": {"launch": round(ht["decode_launch_ms"] / max(ht["passes"], 1), 4), "wait": round(ht["decode_wait_ms"] / max(ht["passes"], 1), 4)}}), flush=True)
     st.free(); ctx.free()
