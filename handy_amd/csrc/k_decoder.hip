@@ -140,6 +140,15 @@ __global__ __launch_bounds__(256) void dec_cross_attention_kernel(const f16 *__r
         attn_init(s[c]);
     }
     int j = wave * 8 + g;
+    if (NQ == 1) {
+        for (; j + 96 < T; j += 128) {     // four independent key rows (8 x 16-byte loads per lane) in flight per iteration
+            f16x8 k[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { k[u] = *(const f16x8 *)(kp + (long)(j + 32 * u) * 64); v[u] = *(const f16x8 *)(vp + (long)(j + 32 * u) * 64); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) attn_step(s[0], q[0], k[u], v[u]);
+        }
+    }
     for (; j + 32 < T; j += 64) {          // two independent key rows in flight per iteration
         const f16x8 k0 = *(const f16x8 *)(kp + (long)j * 64), v0 = *(const f16x8 *)(vp + (long)j * 64);
         const f16x8 k1 = *(const f16x8 *)(kp + (long)(j + 32) * 64), v1 = *(const f16x8 *)(vp + (long)(j + 32) * 64);
