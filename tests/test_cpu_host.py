@@ -129,3 +129,62 @@ def test_two_process_gather_over_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+# ---------------------------------------------------------------------------------------------- batching front
+class _FakeEngine:
+    """Stands in for the HIP engine so the queueing of handy_amd.manager can run on a CPU."""
+    made = []
+
+    def __init__(self, path, gpu_device, max_batch):
+        self.path, self.max_batch, self.calls, self.closed = path, max_batch, [], False
+        _FakeEngine.made.append(self)
+
+    def transcribe_batch(self, audios, params):
+        import time
+        assert 1 <= len(audios) <= self.max_batch
+        self.calls.append((len(audios), params.language, params.translate))
+        time.sleep(0.02)                       # a batch in flight: later callers pile up behind it
+        if any(a[0] < 0 for a in audios):
+            raise ValueError("bad audio")
+        return [f"  text of {len(a)} samples \n" for a in audios]
+
+    def close(self):
+        self.closed = True
+
+
+def test_transcription_manager_front_coalesces_calls():
+    import threading
+    import numpy as np
+    from handy_amd.manager import TranscriptionManager, normalize_language
+    assert normalize_language("auto") is None and normalize_language("zh-Hans") == "zh" and normalize_language("zh-Hant") == "zh" and normalize_language("fr") == "fr"
+    _FakeEngine.made.clear()
+    tm = TranscriptionManager(max_batch=4, collect_ms=30.0, selected_language="zh-Hant", translate_to_english=True, engine_factory=_FakeEngine)
+    assert tm.transcribe(np.zeros(0, np.float32)) == ""                      # empty audio never needs a model
+    with pytest.raises(RuntimeError, match="Model is not loaded"):
+        tm.transcribe(np.ones(10, np.float32))
+    tm.load_model("/nonexistent/model.bin")
+    assert tm.is_model_loaded()
+    out, errs = {}, {}
+
+    def call(i):
+        try:
+            out[i] = tm.transcribe(np.full(100 + i, 0.5, np.float32))
+        except RuntimeError as e:
+            errs[i] = str(e)
+    th = [threading.Thread(target=call, args=(i,)) for i in range(10)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs and out == {i: f"text of {100 + i} samples" for i in range(10)}      # own result, trimmed
+    eng = _FakeEngine.made[-1]
+    assert sum(c[0] for c in eng.calls) == 10 and len(eng.calls) < 10 and max(c[0] for c in eng.calls) <= 4
+    assert all(c[1] == "zh" and c[2] is True for c in eng.calls)
+    assert tm.batches_run == len(eng.calls) and tm.requests_served == 10
+    # a failing batch reports to its callers, the manager keeps serving
+    with pytest.raises(RuntimeError, match="Whisper transcription failed"):
+        tm.transcribe(np.full(5, -1.0, np.float32))
+    assert tm.transcribe(np.full(7, 1.0, np.float32)) == "text of 7 samples"
+    tm.unload_model()
+    assert eng.closed and not tm.is_model_loaded()
+    with pytest.raises(RuntimeError, match="Model is not loaded"):
+        tm.transcribe(np.ones(10, np.float32))

@@ -186,6 +186,29 @@ def test_full_params_variants_match_oracle(wr, oracle, model_path, variant):
     del keep
 
 
+def test_batching_front_equals_one_call_at_a_time(wr, model_path):
+    """handy_amd.manager.TranscriptionManager: concurrent transcribe() calls are served by shared GPU batches and
+    every caller still gets exactly what a lone call returns (beam search, transcribe-rs defaults)."""
+    import threading
+    from handy_amd.manager import TranscriptionManager
+    path = model_path("micro", decisive=4.0)
+    pcms = [synth_pcm(400 + i, n) for i, n in enumerate((480000, 90000, 250000, 16000 * 7, 480000, 300000))]
+    lone = TranscriptionManager(max_batch=1, collect_ms=0.0, selected_language="en")
+    lone.load_model(path)
+    expect = [lone.transcribe(p) for p in pcms]
+    lone.unload_model()
+    tm = TranscriptionManager(max_batch=8, collect_ms=50.0, selected_language="en")
+    tm.load_model(path)
+    got = [None] * len(pcms)
+    def call(i): got[i] = tm.transcribe(pcms[i])
+    th = [threading.Thread(target=call, args=(i,)) for i in range(len(pcms))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert got == expect and any(len(t) > 0 for t in expect)
+    assert tm.batches_run < len(pcms)
+    tm.unload_model()
+
+
 def test_pipeline_groups_do_not_change_results(wr, model_path):
     """Decoding index ranges of the batch one after the other while the encoder stream still works on the later ones
     (wmi_set_pipeline_groups) changes which sequences share a decoder pass, never their tokens."""
