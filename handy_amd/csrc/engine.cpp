@@ -68,7 +68,7 @@ Engine::~Engine() {
         for (DevBuf *b : {&ews_[l].melT, &ews_[l].h1, &ews_[l].x, &ews_[l].xn, &ews_[l].q, &ews_[l].k, &ews_[l].vt, &ews_[l].att, &ews_[l].hid, &ews_[l].enc16}) b->release();
     }
     for (DevBuf *b : {&pcm_, &mel_raw_, &mel_max_, &mel_utt_dev_, &mel_norm_tmp_, &enc32_,
-                      &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_, &sample_ws_, &splitk_ws_})
+                      &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_, &sample_ws_, &splitk_ws_, &ckvt_})
         b->release();
     meta_host_.release(); out_host_.release(); probs_host_.release(); win_host_.release(); slots_host_.release();
     for (hipEvent_t e : enc_events_) (void)hipEventDestroy(e);
@@ -314,6 +314,7 @@ bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<in
     PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(w.x.as<float>(), model->ln_post_w, model->ln_post_b, w.enc16.as<f16>(), e32, M, d, nullptr, stream_));
     PROF(WMI_K_ENC_GEMM, 2.0 * M * (2.0 * Ld_ * d) * d,
          gemm_cross_kv(w.enc16.as<f16>(), model->xkv_w, M, d, H_, T, Tp, Ld_, ckv_.as<f16>(), model->xkv_b, ds, stream_));
+    if (want_vt_ && ckvt_.p) PROF(WMI_K_ENC_OTHER, (double)E * Ld_ * T * d * 4, cross_v_transpose(ckv_.as<f16>(), ds, E, ckvt_.as<f16>(), H_, T, Tp, Ld_, stream_));
     prof_stream_ = this->stream_;
     enc_T_ = T;
     n_encode += E;
@@ -393,11 +394,13 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     // one packed metadata upload
     char *hb = meta_host_.as<char>();
     // runs of consecutive rows of one utterance (beams, prompt tokens), cut at 8: they share one sweep over the cross K/V
+    const bool mq = want_vt_ && ckvt_.p;                 // MFMA kernel over the transposed V: groups of up to 16 rows
+    const int group_cap = mq ? 16 : 8;
     xgroups_.clear();
     int max_group = 1;
     for (int r = 0; r < R;) {
         int e = r + 1;
-        while (e < R && e - r < 8 && rows[e].utt == rows[r].utt) e++;
+        while (e < R && e - r < group_cap && rows[e].utt == rows[r].utt) e++;
         xgroups_.push_back(int2{r, e - r});
         max_group = std::max(max_group, e - r);
         r = e;
@@ -461,6 +464,9 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         } else {
             PROF(WMI_K_DEC_GEMM, w1, gemm_f16(dxn_.as<f16>(), d, D.xq, d, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_));
         }
+        if (mq && max_group > 1)
+            PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp, NG, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
+        else
         PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp, NG, max_group, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
         if (fused_ln) { if (!residual_ln(datt_.as<f16>(), d, D.xo, D.bxo, s_dd, D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R)) return false; }
         else {
@@ -858,6 +864,9 @@ int Engine::Run::run(const float *const *pcm, const int *n, int B, bool on_devic
     if (P.strategy == WHISPER_SAMPLING_BEAM_SEARCH && P.beam_search.beam_size > E.max_dec_) { log_msg(2, "whisper_full: beam size %d exceeds the state's %d decoders\n", P.beam_search.beam_size, E.max_dec_); return -4; }
     if (P.audio_ctx > M.hp.n_audio_ctx) { log_msg(2, "whisper_full: audio_ctx is larger than the maximum allowed (%d > %d)\n", P.audio_ctx, M.hp.n_audio_ctx); return -5; }
     E.exp_n_audio_ctx = P.audio_ctx;
+    // several sequences per utterance (beams, best_of): keep a transposed copy of the cross V so that their cross-attention
+    // can share one MFMA sweep over K and V; without the memory for it the shared-sweep VALU kernel is used
+    E.want_vt_ = n_decoders > 1 && E.ckvt_.ensure((size_t)E.max_utts_ * E.Ld_ * E.H_ * 64 * E.Tp_full_ * sizeof(f16));
     n_max = M.hp.n_text_ctx / 2 - 4;
     single = B == 1;
     initial_prompt_tokens.clear();

@@ -150,6 +150,8 @@ private:
     hipEvent_t next_enc_event();
     int enc_T_ = 0;                  // audio context of the last encode (cross K/V length)
     DevBuf ckv_;
+    DevBuf ckvt_;                    // transposed copy of the cross V, kept only while runs decode several sequences per utterance
+    bool want_vt_ = false;
     int Tp_full_ = 0;
 
     // decoder workspace

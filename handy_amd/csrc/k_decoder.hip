@@ -166,6 +166,149 @@ __global__ __launch_bounds__(256) void dec_cross_attention_kernel(const f16 *__r
         if (NQ > 1) __syncthreads();                                                                // red is reused by the next row
     }
 }
+// ---- cross-attention for groups of rows on MFMA (beam search: the beams of an utterance share its K and V)
+// V of the cross cache, transposed per (slot, layer, head): vt[dim][key]. Made once per encoded window, only for
+// runs that decode several sequences per utterance.
+__global__ __launch_bounds__(256) void cross_v_transpose_kernel(const f16 *__restrict__ ckv, const int *__restrict__ slots, f16 *__restrict__ vt,
+                                                                int H, int T, int Tp, int n_layer) {
+    __shared__ f16 tile[64][66];
+    const int t0 = blockIdx.x * 64, head = blockIdx.y % H, layer = blockIdx.y / H;
+    const long slot = slots[blockIdx.z];
+    const f16 *v = ckv + ((((slot * n_layer + layer) * 2 + 1) * H + head) * (long)Tp) * 64;
+    f16 *o = vt + (((slot * n_layer + layer) * H + head) * 64L) * Tp;
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+        const int t = i >> 3, c = i & 7;
+        f16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t0 + t < T) x = *(const f16x8 *)(v + (long)(t0 + t) * 64 + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) tile[t][c * 8 + e] = x[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+        const int e = i >> 3, c = i & 7;
+        f16x8 x;
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = tile[c * 8 + k][e];
+        *(f16x8 *)(o + (long)e * Tp + t0 + c * 8) = x;         // t0 + 64 <= Tp: Tp is a multiple of 128
+    }
+}
+bool cross_v_transpose(const f16 *ckv, const int *slots, int n_slots, f16 *vt, int H, int T, int Tp, int n_layer, hipStream_t st) {
+    if (n_slots <= 0) return true;
+    hipLaunchKernelGGL(cross_v_transpose_kernel, dim3((T + 63) / 64, H * n_layer, n_slots), dim3(256), 0, st, ckv, slots, vt, H, T, Tp, n_layer);
+    return hipGetLastError() == hipSuccess;
+}
+
+// One workgroup = one (group of <= 16 rows of one utterance, head); its 4 waves take the 32-key tiles round-robin.
+//   S^T[key][row] = K Q^T    v_mfma_f32_16x16x32_f16, K rows straight from global memory as the A operand (16 B per lane),
+//                            Q as the B operand: a lane ends up with one row's scores for 4 keys of each 16-key half
+//   softmax                  running maximum per row kept equal in the 4 lanes that share the row (two shuffles per
+//                            tile), because all of them feed one accumulator
+//   O^T[dim][row] += V^T P^T P^T goes from the score registers straight into the B operand; V^T comes from the transposed
+//                            copy in the key order that layout implies (two 8-byte loads per lane and 16 dims)
+// Every K and V byte of the head is read once per group; the four waves' partial results meet in LDS.
+__global__ __launch_bounds__(256) void dec_cross_attention_mq_kernel(const f16 *__restrict__ qb, const f16 *__restrict__ ckv, const f16 *__restrict__ vt,
+                                                                     const DecRow *__restrict__ rows, const int2 *__restrict__ groups, int d, int H, int T, int Tp,
+                                                                     int n_layer, int layer, f16 *__restrict__ att) {
+    __shared__ float red[4][16][66];       // per wave and row: 64 dims, running maximum, sum
+    const int head = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int m0 = groups[blockIdx.y].x, cnt = groups[blockIdx.y].y;
+    const long slot = rows[m0].utt;
+    const f16 *kp = ckv + ((((slot * n_layer + layer) * 2 + 0) * H + head) * (long)Tp) * 64;
+    const f16 *vp = vt + (((slot * n_layer + layer) * H + head) * 64L) * Tp;
+    f16x8 qf[2];
+    {
+        const f16 *q = qb + (long)(m0 + (n < cnt ? n : 0)) * d + head * 64 + g * 8;
+        qf[0] = *(const f16x8 *)q; qf[1] = *(const f16x8 *)(q + 32);
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = f32x4{0, 0, 0, 0};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int n_tiles = (T + 31) / 32;
+    struct Frags { f16x8 k[2][2]; f16x4 v[4][2]; };
+    auto load_tile = [&](Frags &f, int t) {
+        const int key0 = t * 32;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) f.k[u][ks] = *(const f16x8 *)(kp + (long)(key0 + u * 16 + n) * 64 + ks * 32 + g * 8);
+#pragma unroll
+        for (int db = 0; db < 4; db++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) f.v[db][u] = *(const f16x4 *)(vp + (long)(db * 16 + n) * Tp + key0 + u * 16 + g * 4);
+    };
+    auto compute_tile = [&](const Frags &f, int t) {
+        f32x4 s[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            s[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.k[u][0], qf[0], f32x4{0, 0, 0, 0}, 0, 0, 0);
+            s[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.k[u][1], qf[1], s[u], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (t * 32 + u * 16 + g * 4 + r >= T) s[u][r] = -INFINITY;
+                mx = fmaxf(mx, s[u][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);           // exp(-inf) = 0 on the first tile
+        f16x8 pf;
+        float ls = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const float p = __expf(s[u][r] - m_new); ls += p; pf[u * 4 + r] = (f16)p; }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+            o[db] *= alpha;
+            const f16x8 va = {f.v[db][0][0], f.v[db][0][1], f.v[db][0][2], f.v[db][0][3], f.v[db][1][0], f.v[db][1][1], f.v[db][1][2], f.v[db][1][3]};
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pf, o[db], 0, 0, 0);
+        }
+    };
+    // two register sets: the next tile of this wave is in flight while the current one is multiplied
+    Frags fa, fb;
+    int t = wave;
+    if (t < n_tiles) load_tile(fa, t);
+    for (; t < n_tiles; t += 8) {
+        if (t + 4 < n_tiles) load_tile(fb, t + 4);
+        compute_tile(fa, t);
+        if (t + 4 < n_tiles) {
+            if (t + 8 < n_tiles) load_tile(fa, t + 8);
+            compute_tile(fb, t + 4);
+        }
+    }
+    l_run += __shfl_xor(l_run, 16); l_run += __shfl_xor(l_run, 32);
+#pragma unroll
+    for (int db = 0; db < 4; db++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][n][db * 16 + g * 4 + r] = o[db][r];
+    if (g == 0) { red[wave][n][64] = m_run; red[wave][n][65] = l_run; }
+    __syncthreads();
+    for (int i = tid; i < cnt * 64; i += 256) {
+        const int row = i >> 6, e = i & 63;
+        float mn = -INFINITY;
+        for (int w = 0; w < 4; w++) mn = fmaxf(mn, red[w][row][64]);
+        float l = 0.0f, a = 0.0f;
+        for (int w = 0; w < 4; w++) {
+            const float mw = red[w][row][64];
+            const float f = mw == -INFINITY ? 0.0f : __expf(mw - mn);
+            l += red[w][row][65] * f; a += red[w][row][e] * f;
+        }
+        att[(long)(m0 + row) * d + head * 64 + e] = (f16)(a / l);
+    }
+}
+bool dec_cross_attention_mq(const f16 *q, const f16 *ckv, const f16 *vt, const DecRow *rows, const int2 *groups, int n_groups, int d, int H, int T, int Tp,
+                            int n_layer, int layer, f16 *att, hipStream_t st) {
+    if (n_groups <= 0) return true;
+    hipLaunchKernelGGL(dec_cross_attention_mq_kernel, dim3(H, n_groups), dim3(256), 0, st, q, ckv, vt, rows, groups, d, H, T, Tp, n_layer, layer, att);
+    return hipGetLastError() == hipSuccess;
+}
+
 bool dec_cross_attention(const f16 *q, const f16 *ckv, const DecRow *rows, const int2 *groups, int n_groups, int max_group, int M, int d, int H, int T, int Tp,
                          int n_layer, int layer, f16 *att, hipStream_t st) {
     if (M <= 0) return true;

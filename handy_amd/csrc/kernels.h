@@ -71,6 +71,10 @@ bool sample_rows(float *logits, long ld, int R, const SampleRow *srow, const Voc
                  SampleOut *out, TopkOut *topk, int topk_stride, float *probs, bool any_extra, void *workspace, hipStream_t st);
 // copy KV page contents in every layer (beam fork of a partially filled page): pairs of (src_page, dst_page)
 bool copy_pages(f16 *kpool, f16 *vpool, long layer_stride, int n_layer, const int2 *pairs, int n_pairs, int H, hipStream_t st);
+// MFMA form for groups of up to 16 rows (count in groups[].y), reading V through its transposed copy vt[slot][layer][head][64][Tp]
+bool cross_v_transpose(const f16 *ckv, const int *slots, int n_slots, f16 *vt, int H, int T, int Tp, int n_layer, hipStream_t st);
+bool dec_cross_attention_mq(const f16 *q, const f16 *ckv, const f16 *vt, const DecRow *rows, const int2 *groups, int n_groups, int d, int H, int T, int Tp,
+                            int n_layer, int layer, f16 *att, hipStream_t st);
 // consumers of split-K partials ws[split][M][N] (summed in split order, then the same arithmetic as the fused epilogues)
 bool splitk_residual_ln(float *x, const float *ws, int splits, const float *bias, const float *ln_w, const float *ln_b, f16 *out, int M, int d,
                         const int *gather, int n_out, hipStream_t st);         // x[m] += sum + bias; out[i] = LN(x[gather ? gather[i] : i])
