@@ -100,13 +100,18 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
         const int sw = (srow >> 1) & 7;
         *(f16x8 *)(kb + srow * 128 + (((sc) ^ sw) << 4)) = pk[0];
         *(f16x8 *)(kb + srow * 128 + (((sc + 1) ^ sw) << 4)) = pk[1];
-        const int sv = (srow >> 1) & 15;
+        // V^T tile: the P operand of the PV MFMA holds keys {16s + 4h + b, 16s + 8 + 4h + b} (b < 4) in one fragment, so the two
+        // 4-key chunks that meet there are stored side by side (chunk bits a, h swapped) and come back as ONE 16-byte read
+        const int sv = (srow >> 1) & 7;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const f16x4 lo = {pv[i][0], pv[i][1], pv[i][2], pv[i][3]}, hi = {pv[i][4], pv[i][5], pv[i][6], pv[i][7]};
-            const int c8 = (sc + i) * 2;
-            *(f16x4 *)(vb + srow * 128 + (((c8) ^ sv) << 3)) = lo;
-            *(f16x4 *)(vb + srow * 128 + (((c8 + 1) ^ sv) << 3)) = hi;
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int c8 = (sc + i) * 2 + hh;                                  // 4-key chunk index = 8kh + 4s + 2a + h
+                const int pi = (c8 & ~3) | ((c8 & 1) << 1) | ((c8 >> 1) & 1);      // -> 8kh + 4s + 2h + a
+                *(f16x4 *)(vb + srow * 128 + ((((pi >> 1) ^ sv) << 1 | (pi & 1)) << 3)) = hh ? hi : lo;
+            }
         }
     };
 
@@ -175,13 +180,11 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
         for (int kh = 0; kh < 2; kh++)
 #pragma unroll
             for (int sidx = 0; sidx < 2; sidx++) {
-                const int c8 = kh * 8 + 4 * sidx + h;
+                const int p16 = kh * 4 + 2 * sidx + h;
 #pragma unroll
                 for (int blk = 0; blk < 2; blk++) {
-                    const int row = blk * 32 + r, sv = (row >> 1) & 15;
-                    const f16x4 lo = *(const f16x4 *)(vb + row * 128 + ((c8 ^ sv) << 3));
-                    const f16x4 hi = *(const f16x4 *)(vb + row * 128 + (((c8 + 2) ^ sv) << 3));
-                    const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const int row = blk * 32 + r;
+                    const f16x8 vf = *(const f16x8 *)(vb + row * 128 + ((p16 ^ ((row >> 1) & 7)) << 4));
                     if (blk == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][sidx], o0, 0, 0, 0);
                     else o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][sidx], o1, 0, 0, 0);
                 }
