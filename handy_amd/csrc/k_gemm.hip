@@ -323,7 +323,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // groups instead of in one burst after the barrier; kFirstHalf confines that to the first k-half of the step,
 // so the loads get the second half's MFMAs as extra time to land. Harness-only builds: kNoLoads / kNoLdsReads /
 // kNoMfma drop one ingredient of the loop (ablation timing), kStamps records s_memtime per loop section.
-enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
+enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
@@ -334,7 +334,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;     // 16x16 tiles per wave along m and n
     constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW, LPS = LA + LB;   // LDS-DMA instructions per wave per stage
     static_assert(LA >= 1 && LB >= 1, "tile too small for the wave count");
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations (M0) and tile offsets need no VALU
     int bm, bn;
     tile_coords(blockIdx.x, (M + BM - 1) / BM, N / BN, gm, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
@@ -366,8 +367,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
                                              (__attribute__((address_space(3))) void *)(base + A_BYTES + i * NW * 1024), 16, 0, 0);
     };
 
+    // kBufferLoad (harness): the same pieces through buffer_load ... lds -- 32-bit lane offsets against a per-workgroup
+    // descriptor, the piece and K-step offsets in an SGPR, so no 64-bit vector address arithmetic per piece
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long)((ABL & kSameTile) ? 0 : m0) * lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)(W + (long)((ABL & kSameTile) ? 0 : n0) * ldw), 0, 0x7fffffff, 0x00020000);
+    const int voff_a = (int)(((long)(wave * 8 + srow) * lda + ((sslot ^ srow) << 3)) * 2), voff_w = (int)(((long)(wave * 8 + srow) * ldw + ((sslot ^ srow) << 3)) * 2);
     auto stage_piece = [&](int kt, int buf, int i, bool is_a) {
         char *base = smem + buf * STAGE + wave * 1024;
+        if (ABL & kBufferLoad) {
+            if (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void *)(base + i * NW * 1024), 16, voff_a, (int)(((long)i * NW * 8 * lda + (long)kt * BK) * 2), 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(base + A_BYTES + i * NW * 1024), 16, voff_w, (int)(((long)i * NW * 8 * ldw + (long)kt * BK) * 2), 0, 0);
+            return;
+        }
         if (is_a)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src + (long)i * NW * 8 * lda + (long)kt * BK),
                                              (__attribute__((address_space(3))) void *)(base + i * NW * 1024), 16, 0, 0);
@@ -507,6 +518,7 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 22: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, e, st);   // loads + MFMA, fragments read once
         case 23: return launch<256, 256, 2, 4, 2, EpiF16, kNoLoads | kNoMfma>(A, lda, W, ldw, M, N, K, e, st);                   // LDS fragment reads only
         case 24: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kNoMfma | kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, e, st);   // loads only
+        case 27: return launch<256, 256, 2, 4, 2, EpiF16, kSpread | kFirstHalf | kBufferLoad>(A, lda, W, ldw, M, N, K, e, st);   // staging through buffer_load ... lds
         case 25: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kNoMfma | kSpread | kFirstHalf | kSameTile>(A, lda, W, ldw, M, N, K, e, st);   // loads only, all L2 hits
         case 26: return launch<256, 256, 2, 4, 2, EpiF16, kSpread | kFirstHalf | kSameTile>(A, lda, W, ldw, M, N, K, e, st);                          // full loop, all L2 hits
         case 11: return launch<256, 256, 2, 4, 2, EpiF16, 1>(A, lda, W, ldw, M, N, K, e, st);   // no global loads in the loop
