@@ -3,16 +3,20 @@
 //   400-point real DFT -> 201 power bins -> filterbank (double accumulation) -> log10(max(., 1e-10))
 //   then, per utterance, clamp to (max - 8) and map to (x + 4) / 4.
 //
-// One workgroup (256 threads) produces 16 consecutive frames:
-//   1. the 2800 input samples the 16 frames share are read once from HBM into LDS (coalesced);
-//   2. each 400-sample real frame is packed into a 200-point complex sequence and transformed in
-//      LDS by a fp32 mixed-radix FFT (200 = 8 x 5 x 5: one radix-8 pass + twiddles, two radix-5
-//      passes), followed by the real-FFT unpacking pass that yields the 201 power bins;
-//   3. the filterbank is applied over each mel bin's nonzero support only (bit-identical to the
+// One workgroup (256 threads) produces 32 consecutive frames:
+//   1. the 5360 input samples the 32 frames share are read once from HBM into LDS (coalesced);
+//   2. each 400-sample real frame is packed into a 200-point complex sequence and transformed by a
+//      fp32 mixed-radix FFT (200 = 8 x 25). The radix-8 pass applies the Hann window as it reads the
+//      samples and keeps its window values and twiddles in registers (a thread serves one residue
+//      n2 for several frames); the 25-point transforms run entirely in registers (5 x 5, constant
+//      twiddles), so a frame crosses LDS twice instead of four times;
+//   3. the real-FFT unpacking computes bins k and 200-k from the same two values and leaves the 201
+//      power values in place of the transform;
+//   4. the filterbank is applied over each mel bin's nonzero support only (bit-identical to the
 //      dense sum, whose other terms are exact zeros), accumulated in double like the reference;
-//   4. raw log10 values go to HBM mel-major and the per-utterance maximum is folded with one
-//      atomicMax per workgroup. The clamp/scale pass is fused into whatever consumes the mel
-//      (encoder window extraction) because it needs the global maximum.
+//   5. raw log10 values go to HBM mel-major (128 B per mel row per workgroup) and the per-utterance
+//      maximum is folded with one atomicMax per workgroup. The clamp/scale pass is fused into
+//      whatever consumes the mel (encoder window extraction) because it needs the global maximum.
 // Bound: HBM. Algorithmic bytes per 30 s utterance: 480000*4 in + n_mel*3000*4 out.
 #include "kernels.h"
 
@@ -20,7 +24,7 @@ namespace wmi {
 
 constexpr int F = kMelFramesPerBlock;          // frames per workgroup
 constexpr int NS = (F - 1) * kHop + kNFft;     // samples shared by the frames
-constexpr int PSTRIDE = 209;                   // power row stride (odd: conflict-free column reads)
+constexpr int ZS = 201;                        // complex elements per frame row in LDS (odd: frames land on different banks)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -66,14 +70,44 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
+// (cos, sin)(2 pi j / 25), the float values of the 400-entry table at 16 j
+__device__ constexpr float kW25[25][2] = {
+    {1.0f, 0.0f}, {0.968583167f, 0.24868989f}, {0.876306653f, 0.481753677f},
+    {0.72896862f, 0.684547126f}, {0.535826802f, 0.844327927f}, {0.309017003f, 0.95105654f},
+    {0.0627905205f, 0.998026729f}, {-0.187381312f, 0.982287228f}, {-0.425779283f, 0.904827058f},
+    {-0.637423992f, 0.770513237f}, {-0.809017003f, 0.587785244f}, {-0.92977649f, 0.368124545f},
+    {-0.992114723f, 0.125333235f}, {-0.992114723f, -0.125333235f}, {-0.92977649f, -0.368124545f},
+    {-0.809017003f, -0.587785244f}, {-0.637423992f, -0.770513237f}, {-0.425779283f, -0.904827058f},
+    {-0.187381312f, -0.982287228f}, {0.0627905205f, -0.998026729f}, {0.309017003f, -0.95105654f},
+    {0.535826802f, -0.844327927f}, {0.72896862f, -0.684547126f}, {0.876306653f, -0.481753677f},
+    {0.968583167f, -0.24868989f},
+};
+
+// |X[k]|^2 of the 400-point real transform from the packed 200-point one: X[k] = E[k] + W400^k O[k],
+// E = (Z[k] + conj Z[200-k])/2, O = (Z[k] - conj Z[200-k])/(2i); a = Z[k], b = Z[200-k], w = (cos, sin)(2 pi k/400)
+__device__ __forceinline__ float unpack_power(float2 a, float2 b, float2 w) {
+    b.y = -b.y;
+    const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+    const float2 dlt = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    const float2 o = mul_mi(dlt);
+    const float2 xo = cmul(o, make_float2(w.x, -w.y));
+    const float re = e.x + xo.x, im = e.y + xo.y;
+    return re * re + im * im;
+}
+
+constexpr int NSR = (NS + 255) / 256;          // sample loads per thread
+constexpr int kMaxPackedFilter = 1024;         // nonzero-support weights staged in LDS (Whisper's filterbanks hold ~400)
+
+// PACKED: the filterbank's nonzero supports, concatenated, sit in LDS (meta word per mel bin: lo | count << 8 | offset << 16);
+// otherwise (a model file with a dense or very wide table) the weights are read from the dense table in global memory.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void mel_raw_kernel(const float *__restrict__ pcm, const MelUtt *__restrict__ utts, MelTables tb,
                                                       float *__restrict__ mel_out, unsigned *__restrict__ mel_max) {
-    __shared__ float2 z[F * 200];
-    __shared__ float sp[F * PSTRIDE];          // samples first (NS <= F*PSTRIDE), then the power spectra
-    __shared__ float2 tw[400];
-    __shared__ float hann[400];
+    __shared__ __align__(16) float smp[NSR * 256];
+    __shared__ float2 z[F * ZS];
+    __shared__ float fw[PACKED ? kMaxPackedFilter : 1];
+    __shared__ int fmeta[PACKED ? 128 : 1];
     __shared__ float wmax[4];
-    static_assert(NS <= F * PSTRIDE, "sample buffer too small");
     const MelUtt u = utts[blockIdx.y];
     const int f0 = blockIdx.x * F;
     if (f0 >= u.n_frames) return;
@@ -84,105 +118,128 @@ __global__ __launch_bounds__(256) void mel_raw_kernel(const float *__restrict__ 
         if (tid == 0) atomicMax(mel_max + blockIdx.y, ordered_bits(-10.0f));
         return;
     }
-    for (int i = tid; i < 400; i += 256) { tw[i] = tb.tw400[i]; hann[i] = tb.hann[i]; }
-    const float *x = pcm + u.pcm_off;
-    for (int i = tid; i < NS; i += 256) {
-        const long p = (long)f0 * kHop + i;
-        float v = 0.0f;
-        if (p < 200) { const long s = 200 - p; v = s < u.n ? x[s] : 0.0f; }
-        else { const long s = p - 200; v = s < u.n ? x[s] : 0.0f; }
-        sp[i] = v;
-    }
-    __syncthreads();
-    // windowed frame -> packed complex sequence z[m] = w[2m] x[2m] + i w[2m+1] x[2m+1]
-    for (int i = tid; i < F * 200; i += 256) {
-        const int f = i / 200, m = i - f * 200;
-        const float *s = sp + f * kHop + 2 * m;
-        z[i] = make_float2(hann[2 * m] * s[0], hann[2 * m + 1] * s[1]);
-    }
-    __syncthreads();
-    // pass 1: 25 radix-8 butterflies per frame over n = 25*n1 + n2, twiddle W200^(n2*k1), store at [k1][n2]
-    for (int i = tid; i < F * 25; i += 256) {
-        const int f = i / 25, n2 = i - f * 25;
-        float2 *zz = z + f * 200 + n2;
-        float2 v[8];
-#pragma unroll
-        for (int a = 0; a < 8; a++) v[a] = zz[25 * a];
-        dft8(v);
-#pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) { const float2 w = tw[(2 * n2 * k1) % 400]; v[k1] = cmul(v[k1], make_float2(w.x, -w.y)); }
-#pragma unroll
-        for (int k1 = 0; k1 < 8; k1++) zz[25 * k1] = v[k1];
-    }
-    __syncthreads();
-    // pass 2a: per (k1, b) radix-5 over a of y[5a+b], twiddle W25^(b*c), store at [c][b]
-    for (int i = tid; i < F * 40; i += 256) {
-        const int f = i / 40, r = i - f * 40, k1 = r / 5, b = r - k1 * 5;
-        float2 *zz = z + f * 200 + k1 * 25 + b;
-        float2 v[5];
-#pragma unroll
-        for (int a = 0; a < 5; a++) v[a] = zz[5 * a];
-        dft5(v);
-#pragma unroll
-        for (int c = 1; c < 5; c++) { const float2 w = tw[(16 * b * c) % 400]; v[c] = cmul(v[c], make_float2(w.x, -w.y)); }
-#pragma unroll
-        for (int c = 0; c < 5; c++) zz[5 * c] = v[c];
-    }
-    __syncthreads();
-    // pass 2b: per (k1, c) radix-5 over b; result k = k1 + 8*(c + 5e). All reads before any write.
+    // The samples of this workgroup's frames: padded position p = 160 f0 + i holds sample |p - 200| (reflection on the left),
+    // zero past the end. All loads are issued before the first is consumed; the buffer descriptor's range check supplies the
+    // zeros (its record count is the number of samples left from the first one this workgroup can touch).
     {
-        float2 v[3][5]; int base[3];
+        const long s0 = f0 ? (long)f0 * kHop - 200 : 0;
+        const long left = (long)u.n - s0;
+        const int nrec = left <= 0 ? 0 : (left > NSR * 256 ? NSR * 256 : (int)left);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(pcm + u.pcm_off + s0), 0, nrec * 4, 0x00020000);
+        float v[NSR];
 #pragma unroll
-        for (int rnd = 0; rnd < 3; rnd++) {
-            const int i = tid + rnd * 256;
-            base[rnd] = -1;
-            if (i < F * 40) {
-                const int f = i / 40, r = i - f * 40, k1 = r / 5, c = r - k1 * 5;
-                const float2 *zz = z + f * 200 + k1 * 25 + c * 5;
+        for (int r = 0; r < NSR; r++) {
+            const int i = tid + 256 * r;
+            const int idx = f0 ? i : (i < 200 ? 200 - i : i - 200);
+            v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, idx * 4, 0, 0));
+        }
+        if (PACKED) {
+            for (int i = tid; i < tb.n_packed; i += 256) fw[i] = tb.fpacked[i];
+            if (tid < tb.n_mel) fmeta[tid] = tb.fmeta[tid];
+        }
 #pragma unroll
-                for (int b = 0; b < 5; b++) v[rnd][b] = zz[b];
-                dft5(v[rnd]);
-                base[rnd] = f * 200 + k1 + 8 * c;
+        for (int r = 0; r < NSR; r++) smp[tid + 256 * r] = v[r];
+    }
+    // register tables: pass 1's window values and twiddles for residue n2, the unpacking pass's twiddles for bins k and 200-k
+    const int n2 = tid % 25, fg = tid / 25;
+    float2 hw[8], w8[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        hw[a] = make_float2(tb.hann[50 * a + 2 * n2], tb.hann[50 * a + 2 * n2 + 1]);
+        const float2 w = tb.tw400[(2 * n2 * a) % 400];
+        w8[a] = make_float2(w.x, -w.y);
+    }
+    const int uk = tid % 101, ug = tid / 101;
+    const float2 wk = tb.tw400[uk], wr = tb.tw400[200 - uk];
+    __syncthreads();
+    // pass 1: packed sequence z[m] = w[2m] x[2m] + i w[2m+1] x[2m+1], m = 25 a + n2; radix-8 over a, twiddle W200^(n2 k1),
+    // stored at [k1][n2]. Thread (n2, fg) serves frames fg, fg + 8, ...
+    if (fg < 8) {
+#pragma unroll 2
+        for (int f = fg; f < F; f += 8) {
+            const float *sp = smp + f * kHop + 2 * n2;
+            float2 v[8];
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                const float2 sv = *reinterpret_cast<const float2 *>(sp + 50 * a);
+                v[a] = make_float2(hw[a].x * sv.x, hw[a].y * sv.y);
+            }
+            dft8(v);
+#pragma unroll
+            for (int k1 = 1; k1 < 8; k1++) v[k1] = cmul(v[k1], w8[k1]);
+            float2 *zz = z + f * ZS + n2;
+#pragma unroll
+            for (int k1 = 0; k1 < 8; k1++) zz[25 * k1] = v[k1];
+        }
+    }
+    __syncthreads();
+    // pass 2: thread (frame, k1) transforms its 25 values in registers: radix-5 over a of y[5a+b], twiddle W25^(b c),
+    // radix-5 over b; result k = k1 + 8 (c + 5 e). Every thread has read its row before any thread writes.
+    {
+        const int f = tid >> 3, k1 = tid & 7;
+        float2 t[25];
+        {
+            const float2 *y = z + f * ZS + k1 * 25;
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+                float2 v[5];
+#pragma unroll
+                for (int a = 0; a < 5; a++) v[a] = y[5 * a + b];
+                dft5(v);
+                t[b] = v[0];
+#pragma unroll
+                for (int c = 1; c < 5; c++) t[5 * c + b] = cmul(v[c], make_float2(kW25[(b * c) % 25][0], -kW25[(b * c) % 25][1]));
             }
         }
         __syncthreads();
+        float2 *zo = z + f * ZS + k1;
 #pragma unroll
-        for (int rnd = 0; rnd < 3; rnd++)
-            if (base[rnd] >= 0) {
+        for (int c = 0; c < 5; c++) {
+            float2 v[5];
 #pragma unroll
-                for (int e = 0; e < 5; e++) z[base[rnd] + 40 * e] = v[rnd][e];
-            }
+            for (int b = 0; b < 5; b++) v[b] = t[5 * c + b];
+            dft5(v);
+#pragma unroll
+            for (int e = 0; e < 5; e++) zo[8 * c + 40 * e] = v[e];
+        }
     }
     __syncthreads();
-    // real-FFT unpacking: X[k] = E[k] + W400^k O[k], E = (Z[k] + conj Z[200-k])/2, O = (Z[k] - conj Z[200-k])/(2i)
-    for (int i = tid; i < F * kNBins; i += 256) {
-        const int f = i / kNBins, k = i - f * kNBins;
-        const float2 a = z[f * 200 + (k == 200 ? 0 : k)];
-        float2 b = z[f * 200 + ((200 - k) % 200)];
-        b.y = -b.y;
-        const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-        const float2 dlt = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-        const float2 o = mul_mi(dlt);
-        const float2 w = tw[k % 400];
-        const float2 xo = cmul(o, make_float2(w.x, -w.y));
-        const float re = e.x + xo.x, im = e.y + xo.y;
-        sp[f * PSTRIDE + k] = re * re + im * im;
+    // real-FFT unpacking in place: thread (k, g) turns Z[k], Z[200-k] of frames g, g + 2, ... into the two power values;
+    // bin k ends up in z[k].x (bin 200 in the row's spare 201st element)
+    if (tid < 202) {
+#pragma unroll 4
+        for (int f = ug; f < F; f += 2) {
+            float2 *zf = z + f * ZS;
+            const float2 a = zf[uk], b = zf[uk == 0 ? 0 : 200 - uk];
+            const float pk = unpack_power(a, b, wk), pr = unpack_power(b, a, wr);
+            zf[uk].x = pk;
+            if (uk != 100) zf[200 - uk].x = pr;
+        }
     }
     __syncthreads();
     float lmax = -1e30f;
     {
         const int f = tid & (F - 1), jg = tid / F;
-        const float *pw = sp + f * PSTRIDE;
-        for (int j = jg; j < tb.n_mel; j += 256 / F) {
-            const int lo = tb.flo[j], hi = tb.fhi[j];
-            const float *fl = tb.filters + j * kNBins;
-            double sum = 0.0;
-            for (int k = lo; k < hi; k++) sum += (double)(pw[k] * fl[k]);
-            // log10 through the hardware log2 (about 1 ulp of fp32, i.e. ~1e-6 absolute here, against a parity bound of
-            // 1e-3); a double-precision log10 per output value would be most of this kernel's instructions
+        const float *pw = reinterpret_cast<const float *>(z + f * ZS);
+        // log10 through the hardware log2 (about 1 ulp of fp32, i.e. ~1e-6 absolute here, against a parity bound of 1e-3);
+        // a double-precision log10 per output value would be most of this kernel's instructions
+        auto emit = [&](int j, double sum) {
             const float v = __builtin_amdgcn_logf((float)(sum > 1e-10 ? sum : 1e-10)) * 0.30102999566398119521f;
             out[(long)j * u.n_frames + f0 + f] = v;
             lmax = fmaxf(lmax, v);
+        };
+        for (int j = jg; j < tb.n_mel; j += 256 / F) {
+            double sum = 0.0;
+            if (PACKED) {
+                const int m = fmeta[j], cnt = (m >> 8) & 255;
+                const float *w = fw + (m >> 16), *p = pw + 2 * (m & 255);
+                for (int k = 0; k < cnt; k++) sum += (double)(p[2 * k] * w[k]);
+            } else {
+                const int lo = tb.flo[j], hi = tb.fhi[j];
+                const float *fl = tb.filters + j * kNBins;
+                for (int k = lo; k < hi; k++) sum += (double)(pw[2 * k] * fl[k]);
+            }
+            emit(j, sum);
         }
     }
     for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
@@ -194,7 +251,9 @@ __global__ __launch_bounds__(256) void mel_raw_kernel(const float *__restrict__ 
 bool mel_raw(const float *pcm, const MelUtt *utts, int n_utt, int max_blocks_per_utt, const MelTables &tb, float *mel_raw_out, unsigned *mel_max, hipStream_t st) {
     if (n_utt <= 0 || max_blocks_per_utt <= 0) return true;
     WMI_HIP_OK(hipMemsetAsync(mel_max, 0, sizeof(unsigned) * n_utt, st));
-    hipLaunchKernelGGL(mel_raw_kernel, dim3(max_blocks_per_utt, n_utt), dim3(256), 0, st, pcm, utts, tb, mel_raw_out, mel_max);
+    if (tb.n_mel > 128) return false;
+    if (tb.fpacked) hipLaunchKernelGGL(mel_raw_kernel<true>, dim3(max_blocks_per_utt, n_utt), dim3(256), 0, st, pcm, utts, tb, mel_raw_out, mel_max);
+    else hipLaunchKernelGGL(mel_raw_kernel<false>, dim3(max_blocks_per_utt, n_utt), dim3(256), 0, st, pcm, utts, tb, mel_raw_out, mel_max);
     return hipGetLastError() == hipSuccess;
 }
 

@@ -27,6 +27,9 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
 struct MelTables {           // device-resident constants of one model
     const float *filters;    // [n_mel][201] dense table from the model file
     const int   *flo, *fhi;  // per mel bin: nonzero support [lo, hi)
+    const float *fpacked;    // the supports' weights, concatenated in mel order; null when they exceed the kernel's LDS table
+    const int   *fmeta;      // per mel bin: lo | count << 8 | offset into fpacked << 16
+    int n_packed;
     const float *hann;       // [400]
     const float2 *tw400;     // [400] (cos, sin)(2*pi*m/400)
     int n_mel;
@@ -38,7 +41,7 @@ struct MelUtt {              // one per utterance
     int  n_calc;             // frames that see any audio
     long mel_off;            // offset (floats) of this utterance's raw log-mel
 };
-constexpr int kMelFramesPerBlock = 16;
+constexpr int kMelFramesPerBlock = 32;
 // raw log10 mel (before the max-8 clamp) for every utterance + per-utterance max (as ordered uint)
 bool mel_raw(const float *pcm, const MelUtt *utts, int n_utt, int max_blocks_per_utt, const MelTables &tb, float *mel_raw, unsigned *mel_max, hipStream_t st);
 // normalised copy: out[j][i] for i < n_out frames (clamp to max-8, (x+4)/4); frames past n_frames read as -10

@@ -247,6 +247,17 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
         M->mel.filters = U.put(filters.data(), filters.size());
         M->mel.flo = U.put(lo.data(), lo.size()); M->mel.fhi = U.put(hi.data(), hi.size());
         M->mel.hann = U.put(hann.data(), hann.size()); M->mel.tw400 = U.put(tw.data(), tw.size());
+        std::vector<float> packed; std::vector<int> meta(n_mel, 0);
+        for (int j = 0; j < n_mel; j++) {
+            meta[j] = lo[j] | ((hi[j] - lo[j]) << 8) | ((int)packed.size() << 16);
+            packed.insert(packed.end(), filters.begin() + (size_t)j * n_fft + lo[j], filters.begin() + (size_t)j * n_fft + hi[j]);
+        }
+        M->mel.fpacked = nullptr; M->mel.fmeta = nullptr; M->mel.n_packed = 0;
+        if (packed.size() <= 1024 && n_mel <= 128) {           // the log-mel kernel's LDS table; wider tables are read densely
+            M->mel.n_packed = (int)packed.size();
+            if (packed.empty()) packed.push_back(0.0f);
+            M->mel.fpacked = U.put(packed.data(), packed.size()); M->mel.fmeta = U.put(meta.data(), meta.size());
+        }
         M->mel.n_mel = n_mel;
     }
     {   // conv stem: [out][in][3] -> [out][tap*in + c], K padded to the GEMM K-step with zero columns

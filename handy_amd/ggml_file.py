@@ -349,12 +349,13 @@ def n_file_tokens(hp: HParams) -> int:
 
 
 def write_synthetic_model(path: str, arch: str = "micro.en", seed: int = 0, ftype: int = 1,
-                          decisive: float = 1.0, hp: HParams | None = None) -> HParams:
+                          decisive: float = 1.0, hp: HParams | None = None, filters: np.ndarray | None = None) -> HParams:
+    """`filters` replaces the standard [n_mels, 201] mel table (tests of unusual tables)."""
     hp = hp or hparams_for(arch, ftype)
     hp.ftype = ftype
     wtype = FTYPE_TO_TTYPE[ftype % 1000]
     with open(path, "wb") as f:
-        write_header(f, hp, mel_filterbank(hp.n_mels), synthetic_vocab(n_file_tokens(hp)))
+        write_header(f, hp, mel_filterbank(hp.n_mels) if filters is None else filters, synthetic_vocab(n_file_tokens(hp)))
         for name, w in synthetic_tensors(hp, seed, decisive):
             tt = T_F32 if _stays_f32(name, w.shape) else wtype
             if tt not in (T_F32, T_F16) and w.shape[-1] % BLOCK != 0:

@@ -57,6 +57,24 @@ def test_mel_parity(wr, oracle, golden, model_path, arch, n_mels):
     st.free(); ctx.free(); ost.close(); om.close()
 
 
+def test_mel_parity_dense_filter_table(wr, oracle, tmp_path):
+    """A model file whose mel table has no zeros (every bin feeds every mel): the kernel reads such a table densely
+    instead of from its packed on-chip copy; same contract, <= 1e-3 against the oracle."""
+    from handy_amd import ggml_file as gf
+    rng = np.random.default_rng(5)
+    filters = (rng.random((80, 201), dtype=np.float32) * 0.01 + 1e-4).astype(np.float32)
+    path = str(tmp_path / "dense_mel.bin")
+    gf.write_synthetic_model(path, "micro.en", seed=0, filters=filters)
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    ctx = wr.WhisperContext(path); st = ctx.create_state()
+    for seed, n in ((0, 16000), (1, 77777), (2, 480000)):
+        pcm = synth_pcm(seed, n)
+        ref = ost.pcm_to_mel(pcm); st.pcm_to_mel(pcm)
+        assert st.n_len() == ost.n_len_org
+        assert np.abs(st.get_mel(ref.shape[1]) - ref).max() <= 1e-3
+    st.free(); ctx.free(); ost.close(); om.close()
+
+
 @pytest.mark.parametrize("arch", ["micro.en", "micro-v3", "mini"])      # "mini": d = 384, the decoder's split-K GEMMs are active
 def test_encoder_decoder_parity(wr, oracle, golden, model_path, arch):
     path = model_path(arch)
