@@ -7,7 +7,7 @@ import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from bench import model_file
+from bench import model_file, cpu_baseline
 from handy_amd import whisper_rs as wr
 from handy_amd.synth import synth_pcm
 
@@ -44,7 +44,11 @@ for name in which:
     ks = st.kernel_stats()
     st.set_profiling(False)
     n_tok = len(st.batch_tokens(0))
-    print(json.dumps({"workload": name, "arch": arch, "utterances": B, "mode": mode, "tokens_per_utterance": n_tok, "ms_per_step": dt * 1e3, "rtfx": 30.0 * B / dt,
+    extra = {}
+    if name == "tiny":      # the single-clip comparison: the same clip and token count on the host cores (CPU restatement, not whisper.cpp)
+        cb = cpu_baseline(path, tokens, budget_s=20.0)
+        extra = {"cpu_port_ms": 30.0 / cb["value"] * 1e3, "cpu_port_cores": cb["cores"], "cpu_port_sample": cb["sample"]}
+    print(json.dumps({**extra, "workload": name, "arch": arch, "utterances": B, "mode": mode, "tokens_per_utterance": n_tok, "ms_per_step": dt * 1e3, "rtfx": 30.0 * B / dt,
                       "kernel_classes_ms_per_step": {k: round(v["ms"] / steps, 2) for k, v in ks.items()},
                       "cross_attn_TBps": ks["dec_cross_attn"]["work"] / max(ks["dec_cross_attn"]["ms"], 1e-9) / 1e9, "model_file_s": round(t_model, 1),
                       "host_ms_per_pass": {"launch": round(ht["decode_launch_ms"] / max(ht["passes"], 1), 4), "wait": round(ht["decode_wait_ms"] / max(ht["passes"], 1), 4)}}), flush=True)
