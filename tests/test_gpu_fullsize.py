@@ -1,0 +1,110 @@
+"""Full-size checks: Whisper large-v3-turbo (d = 1280, 32 + 4 layers, 128 mels, 51866 tokens; synthetic ggml weights
+of the exact architecture) on the GPU, through the C ABI.
+
+  * one 30 s utterance against the CPU oracle: log-mel, encoder output, cross K/V and the logits of a short prefix
+    (the oracle's encoder takes a few seconds on the GPU box's host cores);
+  * size-independent properties of a full batch: copies of a clip decode to the same tokens wherever they sit in the
+    batch, a second run repeats the first, a batch of one gives the same tokens as the batch of many, and every
+    utterance yields exactly the forced number of tokens.
+"""
+import numpy as np
+import pytest
+
+from handy_amd.synth import synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+ARCH = "large-v3-turbo"
+
+
+@pytest.fixture(scope="module")
+def wr():
+    from handy_amd import whisper_rs
+    whisper_rs.load_library()
+    return whisper_rs
+
+
+@pytest.fixture(scope="module")
+def turbo_path(tmp_path_factory):
+    from handy_amd import ggml_file as gf
+    p = str(tmp_path_factory.mktemp("turbo") / "synthetic-large-v3-turbo.bin")
+    gf.write_synthetic_model(p, ARCH, seed=0, decisive=2.0)
+    return p
+
+
+def test_turbo_one_utterance_matches_oracle(wr, oracle, turbo_path):
+    om = oracle.OracleModel(turbo_path); ost = oracle.OracleState(om)
+    ctx = wr.WhisperContext(turbo_path); st = ctx.create_state()
+    pcm = synth_pcm(11, 30 * 16000)
+    ref_mel = ost.pcm_to_mel(pcm); st.pcm_to_mel(pcm)
+    assert np.abs(st.get_mel(ref_mel.shape[1]) - ref_mel).max() <= 1e-3          # the contract's log-mel bound
+    ref = ost.encode(0)
+    st.encode(0)
+    got = st.encoder_output()
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    print("turbo encoder: max abs err", err, "max |ref|", scale, "ref std", float(ref.std()))
+    # fp16 GEMM operands and activations through 32 layers against the oracle's fp32 activations (fp16-rounded weights in both)
+    assert err <= 2e-2 * max(1.0, scale), (err, scale)
+    for layer in range(om.n_text_layer):
+        k_ref, v_ref = ost.cross_kv(layer)
+        k, v = st.cross_kv(layer)
+        assert np.abs(k - k_ref).max() <= 2e-2 * max(1.0, float(np.abs(k_ref).max()))
+        assert np.abs(v - v_ref).max() <= 2e-2 * max(1.0, float(np.abs(v_ref).max()))
+    sot = om.special("sot")
+    toks = [sot, sot + 1, om.special("transcribe"), om.special("not"), 1000, 2000, 3000, 4000]
+    lref = ost.decode(toks, 0, 0, logits_all=True)
+    lgot = st.decode_logits_all(toks, 0)
+    lerr = float(np.abs(lgot - lref).max())
+    print("turbo logits: max abs err", lerr, "ref std", float(lref.std()))
+    assert lerr <= 2e-2 * max(1.0, float(np.abs(lref).max())), lerr
+    # the decisions a greedy decoder takes from these rows (margins of the synthetic model are far above the error)
+    assert (lgot.argmax(1) == lref.argmax(1)).all()
+    st.free(); ctx.free(); ost.close(); om.close()
+
+
+def test_turbo_greedy_tokens_match_oracle(wr, oracle, turbo_path):
+    """whisper_full on two clips (greedy with timestamps, and no_timestamps with a forced length): token ids, segment
+    times and text identical to the oracle's."""
+    from test_gpu_full import _run_pair, _same
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0); fp.set_language("en")
+    pcms = [synth_pcm(31, 30 * 16000), synth_pcm(32, int(7.5 * 16000))]
+    got, ref, _ = _run_pair(wr, oracle, turbo_path, fp, pcms, max_dec=1, force_n_tokens=12)
+    for u in range(len(pcms)):
+        assert _same(got[u], ref[u]), (u, [g.tokens for g in got[u]], [r["tokens"] for r in ref[u]])
+    fp.set_no_timestamps(True)
+    got, ref, _ = _run_pair(wr, oracle, turbo_path, fp, pcms[1:], max_dec=1, force_n_tokens=20)
+    assert _same(got[0], ref[0])
+
+
+def test_turbo_batch_properties(wr, turbo_path):
+    ctx = wr.WhisperContext(turbo_path)
+    n_force = 24
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0); fp.set_no_timestamps(True); fp.set_language("en")
+    secs = [30.0, 12.3456, 3.0, 29.9, 1.5, 20.0]          # (a clip of 1 s or less yields no window at all, as in whisper.cpp)
+    clips = [synth_pcm(20 + i, int(round(s * 16000))) for i, s in enumerate(secs)]
+    rng = np.random.default_rng(3)
+    order = list(rng.permutation(np.repeat(np.arange(len(clips)), 4)))            # 24 utterances, every clip four times
+    st = ctx.create_batch_state(len(order), 1, 16)
+    st.set_force_tokens(n_force)
+    st.full_batch(fp, [clips[i] for i in order])
+    toks = [list(st.batch_tokens(u)) for u in range(len(order))]
+    for u, t in enumerate(toks):
+        assert len(t) == n_force + 1, (u, len(t))                                  # forced tokens + the end token
+    first = {}
+    for u, c in enumerate(order):
+        if c in first:
+            assert toks[u] == toks[first[c]], f"copies of clip {c} at batch positions {first[c]} and {u} differ"
+        else:
+            first[c] = u
+    st.full_batch(fp, [clips[i] for i in order])
+    assert [list(st.batch_tokens(u)) for u in range(len(order))] == toks           # a second run repeats the first
+    st.free()
+    st1 = ctx.create_batch_state(1, 1, 1)
+    st1.set_force_tokens(n_force)
+    for c in (0, 2, 4):
+        st1.full_batch(fp, [clips[c]])
+        assert list(st1.batch_tokens(0)) == toks[first[c]], f"clip {c}: batch of one differs from the batch of {len(order)}"
+    st1.free(); ctx.free()
