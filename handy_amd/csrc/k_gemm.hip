@@ -187,11 +187,11 @@ template <class Epi> struct is_splitk<Epi, decltype((void)Epi::kSplitK)> { stati
 
 // ------------------------------------------------------------------------------------------ kernel
 // Workgroup id -> output tile. Physical ids p, p+8, ... share an XCD (one private L2 each): every XCD
-// gets a contiguous run of logical ids, and logical ids walk the tile grid in groups of 8 tile rows x
-// all tile columns, column-major inside a group, so the ~32 tiles an XCD works on at one time form an
-// 8 x 4 patch that shares 8 activation panels and 4 weight panels through that L2.
+// gets a contiguous run of logical ids, and logical ids walk the tile grid in groups of 4-6 tile rows x
+// all tile columns, column-major inside a group, so the ~32 tiles an XCD works on at one time form a
+// patch that shares a few activation panels and weight panels through that L2.
 __device__ unsigned long long g_gemm_stamps[2048 * 8 * 8];      // diagnostic builds of the harness only (see gemm_variant)
-int g_tile_group_rows = 8;     // tile rows per group (harness knob; 8 is the shipped value)
+int g_tile_group_rows = 0;     // tile rows per group; 0 = chosen from the tile-column count (harness knob otherwise)
 
 __device__ __forceinline__ void tile_coords(int p, int nbm, int nbn, int GM, int &bm, int &bn) {
     const int nblk = nbm * nbn;
@@ -480,7 +480,9 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
         if (hipFuncSetAttribute((const void *)gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, A, lda, W, ldw, M, N, K, g_tile_group_rows, epi);
+    // rows per L2 group: a group of ~30-80 tiles per XCD measured best on the encoder shapes (6 rows x 5 columns, 5 x 15, 4 x 20)
+    const int nbn = N / BN, gm = g_tile_group_rows > 0 ? g_tile_group_rows : (nbn <= 8 ? 6 : (nbn <= 16 ? 5 : 4));
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, A, lda, W, ldw, M, N, K, gm, epi);
     return hipGetLastError() == hipSuccess;
 }
 
