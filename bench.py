@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--dist-backend", default=os.environ.get("WMI_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend of the result gather; 'gloo' together with --all-ranks-on-device0 rehearses the multi-rank path on one GPU")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--host-pcm", action="store_true",
+                    help="hand the PCM over as host buffers every step (the PCIe-inclusive rate; never the contract's value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed step that profiles every kernel class")
     args = ap.parse_args()
@@ -168,6 +170,7 @@ def main():
     pcm_dev = pcm_dev.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1)[:B].contiguous()
     ptrs = [pcm_dev.data_ptr() + i * n_samp * 4 for i in range(B)]
     ns = [n_samp] * B
+    host_pcm = [pool[i % pool.shape[0]] for i in range(B)] if args.host_pcm else None
 
     from handy_amd.node import gather_token_records, pack_token_records
 
@@ -176,7 +179,9 @@ def main():
     def step(gather=True):
         # S engine states run the same hot path concurrently (own stream, own host thread; ctypes drops the GIL during
         # the call): while one state's decoder streams K/V and weights from HBM, another state's encoder keeps the MFMAs busy
-        if S == 1:
+        if host_pcm is not None:
+            st.full_batch(fp, host_pcm)
+        elif S == 1:
             st.full_batch_device(fp, ptrs, ns)
         else:
             errs = []
@@ -248,7 +253,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"Whisper {args.arch} fp16 (synthetic ggml weights of the exact architecture), {B * S} x 30 s utterances per GPU per step"
                                    f"{'' if S == 1 else f' ({S} concurrent engine states x {B})'}, "
-                                   f"greedy, no_timestamps, {args.tokens} forced tokens per utterance, PCM resident in HBM",
+                                   f"greedy, no_timestamps, {args.tokens} forced tokens per utterance, "
+                                   f"{'PCM handed over as host buffers every step (PCIe-inclusive)' if args.host_pcm else 'PCM resident in HBM'}",
                        "utterances_per_gpu": B * S, "engine_states_per_gpu": S, "pipeline_groups": args.pipeline_groups, "encoder_lanes": args.encoder_lanes, "tokens_per_utterance": args.tokens, "enc_chunk": args.enc_chunk, "parallelism": f"dp{world} by utterance"},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (encoder conv/QKV/out/MLP/cross-KV GEMMs)", "achieved": achieved,
                          "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic,
