@@ -370,6 +370,14 @@ int wmi_get_host_timings(struct whisper_state *s, double *out) {
     return 0;
 }
 int wmi_set_encoder_lanes(struct whisper_state *s, int n) { Engine *e = ENG(s); try { return e && e->set_encoder_lanes(n) ? 0 : -1; } catch (...) { return -1; } }
+void wmi_set_window_cache(struct whisper_state *s, int max_windows) {
+    if (Engine *e = ENG(s)) { try { e->window_cache_cap = max_windows < 0 ? 0 : max_windows; while ((int)e->window_memos.size() > e->window_cache_cap) e->window_memos.pop_front(); } catch (...) {} }
+}
+void wmi_get_window_cache_stats(struct whisper_state *s, long long *hits, long long *stores) {
+    Engine *e = ENG(s);
+    if (hits) *hits = e ? e->window_cache_hits : 0;
+    if (stores) *stores = e ? e->window_cache_stores : 0;
+}
 void wmi_set_pipeline_groups(struct whisper_state *s, int n) { if (Engine *e = ENG(s)) e->pipeline_groups = n < 1 ? 1 : n; }
 void wmi_set_profiling(struct whisper_state *s, int on) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = on != 0; e->profile_mask = ~0u; } }
 void wmi_set_profiling_classes(struct whisper_state *s, unsigned class_mask) { if (Engine *e = ENG(s)) { e->collect_stats(); e->profiling = class_mask != 0; e->profile_mask = class_mask; } }

@@ -603,7 +603,90 @@ struct Engine::Run {
     int n_decoders = 1, n_max = 0, single = 0;
     const Vocab &V;
 
+    // window memo: host PCM of the running group (null when the caller's PCM is on the device), per-utterance sample counts,
+    // the raw log-mel maxima (they enter the normalisation of every window), and a hash of the decoding parameters
+    const float *const *memo_pcm = nullptr;
+    const int *memo_n = nullptr;
+    std::vector<unsigned> memo_mmax;
+    uint64_t memo_params = 0;
+
     Run(Engine &e, whisper_context *c, whisper_state *s, const whisper_full_params &p) : E(e), ctx(c), st(s), P(p), V(e.model->vocab) {}
+
+    static uint64_t mix(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); h *= 0xff51afd7ed558ccdull; return h ^ (h >> 32); }
+    static uint64_t hash_bytes(const void *p, size_t n, uint64_t h) {
+        const unsigned char *b = (const unsigned char *)p;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t v; memcpy(&v, b + i, 8); h = (h ^ v) * 0x9fb21c651e98df25ull; h ^= h >> 29; }
+        uint64_t t = 0; if (i < n) memcpy(&t, b + i, n - i);
+        return mix(h, t ^ (uint64_t)n);
+    }
+    uint64_t params_hash() const {
+        uint64_t h = 0x6d656d6full;
+        const int iv[] = {P.strategy, P.n_max_text_ctx, P.offset_ms, P.duration_ms, P.translate, P.no_context, P.no_timestamps, P.single_segment, P.print_special,
+                          P.max_tokens, P.audio_ctx, P.tdrz_enable, P.suppress_blank, P.suppress_nst, P.greedy.best_of, P.beam_search.beam_size,
+                          E.force_tokens, (int)E.beam_sampled, n_decoders, P.token_timestamps, P.max_len, P.split_on_word};
+        h = hash_bytes(iv, sizeof iv, h);
+        const float fv[] = {P.temperature, P.max_initial_ts, P.length_penalty, P.temperature_inc, P.entropy_thold, P.logprob_thold, P.no_speech_thold, P.beam_search.patience};
+        h = hash_bytes(fv, sizeof fv, h);
+        if (!initial_prompt_tokens.empty()) h = hash_bytes(initial_prompt_tokens.data(), initial_prompt_tokens.size() * sizeof(int), h);
+        return h;
+    }
+    // Key of the window that starts at u.seek, or 0 when the window may not be remembered. Everything its outcome depends on
+    // goes in: the samples under its 3000 frames (with the STFT overlap), the utterance-wide log-mel maximum, the parameters,
+    // the language, the text context and, through the chain value, every earlier window of this call (hence the state of the
+    // decoders' random generators). Only interior windows qualify: near the end of the audio the decode loop looks at the
+    // remaining length.
+    uint64_t window_key(const Utt &u) const {
+        if (E.window_cache_cap <= 0 || !memo_pcm || u.seek + 3100 >= u.seek_end || P.logits_filter_callback) return 0;
+        const long n = memo_n[u.index];
+        const long s0 = std::max(0L, (long)u.seek * kHop - 200), s1 = std::min(n, ((long)u.seek + 3000) * kHop + 200);
+        if (s1 <= s0) return 0;
+        uint64_t h = mix(mix(u.chain, memo_params), ((uint64_t)(uint32_t)u.seek << 32) | (uint32_t)u.lang_id);
+        h = mix(h, ((uint64_t)memo_mmax[u.mel_idx] << 1) | (u.no_timestamps ? 1u : 0u));
+        if (!u.prompt_past.empty()) h = hash_bytes(u.prompt_past.data(), u.prompt_past.size() * sizeof(int), h);
+        h = hash_bytes(memo_pcm[u.index] + s0, (size_t)(s1 - s0) * sizeof(float), h);
+        return h ? h : 1;
+    }
+    // the window at u.seek was decoded before from identical inputs: take its outcome
+    bool reuse_window(Utt &u) {
+        const uint64_t key = window_key(u);
+        if (!key) return false;
+        for (const WindowMemo &m : E.window_memos) {
+            if (m.key != key || m.rng.size() != u.dec.size()) continue;
+            UttResult &res = E.results[u.index];
+            res.segs.insert(res.segs.end(), m.segs.begin(), m.segs.end());
+            res.n_fallbacks += m.n_fallbacks;
+            if (single && P.new_segment_callback && !m.segs.empty()) P.new_segment_callback(ctx, st, (int)m.segs.size(), P.new_segment_callback_user_data);
+            u.prompt_past = m.prompt_past;
+            for (size_t j = 0; j < u.dec.size(); j++) u.dec[j].rng = m.rng[j];
+            u.chain = m.chain_after;
+            u.seek += m.seek_delta;
+            u.encoded_at_seek = false;
+            u.cur_key = 0;
+            u.phase = u.seek + 100 >= u.seek_end ? Phase::Done : Phase::Encode;
+            E.window_cache_hits++;
+            return true;
+        }
+        return false;
+    }
+    void remember_window(Utt &u, size_t n_before, int seek_delta) {
+        uint64_t after = mix(u.chain, mix(u.cur_key ? u.cur_key : 0x77ull + (uint64_t)u.seek, (uint64_t)seek_delta));
+        const std::vector<Segment> &out = E.results[u.index].segs;
+        for (size_t i = n_before; i < out.size(); i++)
+            for (const whisper_token_data &t : out[i].tokens) after = mix(after, (uint64_t)(uint32_t)t.id);
+        if (u.cur_key && E.window_cache_cap > 0) {
+            WindowMemo m;
+            m.key = u.cur_key; m.chain_after = after; m.seek_delta = seek_delta; m.n_fallbacks = E.results[u.index].n_fallbacks - u.fb0;
+            m.segs.assign(out.begin() + n_before, out.end());
+            m.prompt_past = u.prompt_past;
+            for (const Decoder &d : u.dec) m.rng.push_back(d.rng);
+            E.window_memos.push_back(std::move(m));
+            while ((int)E.window_memos.size() > E.window_cache_cap) E.window_memos.pop_front();
+            E.window_cache_stores++;
+        }
+        u.chain = after;
+        u.cur_key = 0;
+    }
 
     void release_decoders(Utt &u) { for (Decoder &d : u.dec) { E.page_release(d.pages); d.n_kv = 0; } }
 
@@ -659,6 +742,8 @@ struct Engine::Run {
     // after the encoder ran for window u.seek
     void begin_window(Utt &u) {
         u.encoded_at_seek = true;
+        u.cur_key = window_key(u);
+        u.fb0 = E.results[u.index].n_fallbacks;
         if (u.seek > u.seek_start && u.seek + 500 >= u.seek_end) u.prompt_past.clear();
         u.it = 0; u.best = 0;
         start_iteration(u);
@@ -841,6 +926,7 @@ struct Engine::Run {
             }
         }
         if (single && P.new_segment_callback && out.size() > n_before) P.new_segment_callback(ctx, st, (int)(out.size() - n_before), P.new_segment_callback_user_data);
+        remember_window(u, n_before, seek_delta);
         release_decoders(u);
         u.seek += seek_delta;
         u.encoded_at_seek = false;
@@ -904,6 +990,12 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
     utts.assign(G, Utt{});
     for (int i = 0; i < G; i++) { Utt &u = utts[i]; u.index = g0 + i; u.slot = i; u.mel_idx = i; init_utt(u); }
     if (hipStreamSynchronize(E.stream_) != hipSuccess) return -2;
+    memo_pcm = nullptr;
+    if (E.window_cache_cap > 0 && !on_device) {
+        memo_mmax.assign(G, 0u);
+        if (hipMemcpy(memo_mmax.data(), E.mel_max_.p, sizeof(unsigned) * G, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+        memo_pcm = pcm; memo_n = n; memo_params = params_hash();
+    }
     E.t_mel_ms += now_ms() - t0;
 
     std::vector<DecRow> rows; std::vector<SampleRow> srows; std::vector<const Decoder *> seqs; std::vector<int2> copies;
@@ -920,6 +1012,7 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
         for (int i = 0; i < G; i++) {
             Utt &u = utts[i];
             if (u.phase == Phase::Encode && u.seek + 100 >= u.seek_end) u.phase = Phase::Done;
+            while (u.phase == Phase::Encode && reuse_window(u)) {}
             if (u.phase == Phase::Encode || u.phase == Phase::LangEncode) need.push_back(i);
         }
         if (!need.empty()) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <random>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "../../include/wmi.h"
@@ -72,8 +73,23 @@ struct Utt {
     int lang_id = 0;
     bool no_timestamps = false;
     bool encoded_at_seek = false; // the cross K/V in the slot already belong to window `seek`
+    uint64_t chain = 0;          // hash of every window of this call so far (inputs and outcomes)
+    uint64_t cur_key = 0;        // key of the window being decoded (0: not eligible for the window memo)
+    int fb0 = 0;                 // fallback count when the window began
     hipEvent_t enc_ev = nullptr; // recorded on the encoder stream behind this utterance's chunk; cleared once seen complete
     int rc = 0;
+};
+
+// Result of one interior 30 s window, kept so that a later call whose audio starts with the same samples (Handy's live
+// coaching re-transcribes the whole growing recording every few seconds) can take the window's outcome instead of
+// encoding and decoding it again. A window is only taken when everything that determines it is identical: see
+// Engine::Run::window_key.
+struct WindowMemo {
+    uint64_t key = 0, chain_after = 0;
+    int seek_delta = 0, n_fallbacks = 0;
+    std::vector<Segment> segs;
+    std::vector<int> prompt_past;
+    std::vector<std::mt19937> rng;
 };
 
 struct PassRowRef { int utt, dec; };   // which (utterance, decoder) a logit row belongs to
@@ -103,6 +119,9 @@ public:
     Model *model;
     std::vector<UttResult> results;
     int force_tokens = 0;
+    int window_cache_cap = 0;            // windows remembered between calls (0 = off)
+    std::deque<WindowMemo> window_memos;
+    long window_cache_hits = 0, window_cache_stores = 0;
     int pipeline_groups = 1;             // index ranges of a batch that decode one after the other while later ones still encode
     int encoder_lanes = 1;               // 2: alternate encoder chunks between two streams/workspaces
     bool set_encoder_lanes(int n);

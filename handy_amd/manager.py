@@ -13,7 +13,9 @@ its observable behaviour --
   * the result text is trimmed                                                (transcription.rs:455)
 
 -- but calls that arrive while a batch is being collected (or while the GPU is busy with the previous one) are
-coalesced into ONE wmi_full_batch over all of them, which is what the batch engine is for. Custom-word correction,
+coalesced into ONE wmi_full_batch over all of them, which is what the batch engine is for. The engine state also keeps a
+memo of finished 30 s windows, so the live-coaching loop, which re-transcribes the whole growing recording every 3 s
+(src-tauri/src/live_coaching.rs:84-97), only pays for the windows that changed. Custom-word correction,
 model download/selection, idle unloading and event emission stay in Handy (out of scope here).
 """
 from __future__ import annotations
@@ -49,12 +51,15 @@ class TranscriptionManager:
     """Thread-safe `transcribe(audio) -> str`; concurrent callers share GPU batches."""
 
     def __init__(self, max_batch: int = 16, collect_ms: float = 3.0, selected_language: str = "auto",
-                 translate_to_english: bool = False, gpu_device: int = 0, engine_factory=None):
+                 translate_to_english: bool = False, gpu_device: int = 0, engine_factory=None, window_cache: int = 16):
         self.max_batch = max(1, max_batch)
         self.collect_ms = collect_ms
         self.selected_language = selected_language
         self.translate_to_english = translate_to_english
         self.gpu_device = gpu_device
+        # 30 s windows remembered between calls: live coaching transcribes the whole growing recording every 3 s
+        # (reference: src-tauri/src/live_coaching.rs:84-97); 0 turns the memo off
+        self.window_cache = window_cache
         # engine_factory(path, gpu_device, max_batch) -> object with transcribe_batch(list of arrays, WhisperInferenceParams) -> list of str
         # and close(); the default drives libwhisper_mi355.so, tests inject a stand-in to exercise the queueing on a CPU
         self._engine_factory = engine_factory or _HipBatchEngine
@@ -71,6 +76,8 @@ class TranscriptionManager:
     def load_model(self, path: str):
         self.unload_model()
         eng = self._engine_factory(path, self.gpu_device, self.max_batch)
+        if self.window_cache > 0 and hasattr(eng, "set_window_cache"):
+            eng.set_window_cache(self.window_cache)
         with self._lock:
             self._engine = eng
             self._stop = False
@@ -159,6 +166,9 @@ class _HipBatchEngine:
         fp = self._proto._full_params(params)
         self.state.full_batch(fp, audios)
         return ["".join(s.text for s in self.state.batch_segments(u)) for u in range(len(audios))]
+
+    def set_window_cache(self, n: int):
+        self.state.set_window_cache(n)
 
     def close(self):
         self.state.free()

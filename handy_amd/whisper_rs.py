@@ -117,7 +117,7 @@ whisper_full_get_token_data whisper_full_get_token_data_from_state whisper_full_
 wmi_init_state_batch wmi_full_batch wmi_batch_n_utts wmi_batch_n_segments wmi_batch_segment_t0 wmi_batch_segment_t1
 wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks
 wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
-wmi_decode_logits_all wmi_debug_gemm wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_version
+wmi_decode_logits_all wmi_debug_gemm wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_version
 """.split()
 
 _lib = None
@@ -191,6 +191,8 @@ def load_library(path: Optional[str] = None):
     L.wmi_debug_gemm.restype = ci; L.wmi_debug_gemm.argtypes = [ci, ci, ci, fp, fp, fp]
     L.wmi_set_profiling.argtypes = [vp, ci]
     L.wmi_set_pipeline_groups.argtypes = [vp, ci]
+    L.wmi_set_window_cache.argtypes = [vp, ci]
+    L.wmi_get_window_cache_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.wmi_set_encoder_lanes.argtypes = [vp, ci]; L.wmi_set_encoder_lanes.restype = ci
     L.wmi_set_profiling_classes.argtypes = [vp, C.c_uint]
     L.wmi_get_kernel_stats.restype = ci; L.wmi_get_kernel_stats.argtypes = [vp, C.POINTER(wmi_kernel_stat)]
@@ -484,6 +486,13 @@ class WhisperState:
     def set_beam_candidates_sampled(self, v: bool): self.L.wmi_set_beam_candidates_sampled(self.h, int(v))
     def set_profiling(self, on: bool): self.L.wmi_set_profiling(self.h, int(on))
     def set_pipeline_groups(self, n: int): self.L.wmi_set_pipeline_groups(self.h, int(n))
+
+    def set_window_cache(self, max_windows: int): self.L.wmi_set_window_cache(self.h, int(max_windows))
+
+    def window_cache_stats(self):
+        h, s_ = C.c_longlong(0), C.c_longlong(0)
+        self.L.wmi_get_window_cache_stats(self.h, C.byref(h), C.byref(s_))
+        return {"hits": h.value, "stores": s_.value}
     def set_encoder_lanes(self, n: int):
         if self.L.wmi_set_encoder_lanes(self.h, int(n)) != 0: raise WhisperError("GenericError", -1)
     def set_profiling_classes(self, names):

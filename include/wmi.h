@@ -46,6 +46,13 @@ WHISPER_API void wmi_set_force_tokens(struct whisper_state *state, int n);
 /* Encoder/decoder overlap inside one wmi_full_batch call: the batch is cut into n index ranges; range k decodes (HBM-bound)
  * while the encoder (MFMA-bound) is still working on ranges k+1.. on a second stream. 1 = encode everything first. Results do
  * not depend on n. */
+/* Window memo for callers that transcribe a growing recording again and again (Handy's live coaching peeks at the
+ * recording every 3 s and transcribes all of it: reference src-tauri/src/live_coaching.rs:84-97). With max_windows > 0 the
+ * state remembers the outcome of interior 30 s windows of host-PCM calls; a later call whose samples, parameters, language,
+ * text context and earlier windows are identical takes a remembered window's segments instead of encoding and decoding it.
+ * The results are the ones the call would have produced without the memo. 0 turns it off and forgets everything. */
+WHISPER_API void wmi_set_window_cache(struct whisper_state *state, int max_windows);
+WHISPER_API void wmi_get_window_cache_stats(struct whisper_state *state, long long *hits, long long *stores);
 WHISPER_API void wmi_set_pipeline_groups(struct whisper_state *state, int n);
 /* 2: alternate the encoder chunks of a batch between two streams with their own workspaces (a second ~0.9 GB set for
  * large-v3-turbo at 16 utterances per chunk), so one chunk's kernels fill the CUs another chunk's draining kernels leave idle.

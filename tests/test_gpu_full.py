@@ -209,6 +209,47 @@ def test_batching_front_equals_one_call_at_a_time(wr, model_path):
     tm.unload_model()
 
 
+def test_window_memo_on_a_growing_recording(wr, model_path):
+    """Handy's live coaching transcribes the whole recording so far every few seconds (reference live_coaching.rs:84-97).
+    With the window memo on, the interior 30 s windows of the earlier calls are taken over instead of being encoded and
+    decoded again, and every call returns exactly what it returns with the memo off -- greedy with temperature fallback
+    and beam search, text context carried between windows."""
+    path = model_path("micro.en")
+    ctx = wr.WhisperContext(path)
+    rng = np.random.default_rng(9)
+    full = synth_pcm(41, 100 * 16000)
+    full[: 8 * 16000] *= 1.0
+    full[8 * 16000:] *= 0.4                    # the loudest stretch is early: the utterance-wide log-mel maximum stops moving
+    lengths = [40, 71, 74, 77, 100]             # seconds recorded at each peek
+    for strategy in (wr.SamplingStrategy.Greedy(2), wr.SamplingStrategy.BeamSearch(3, -1.0)):
+        fp = wr.FullParams(strategy)
+        fp.set_language("en")
+        plain = ctx.create_batch_state(1, 3, 1)
+        memo = ctx.create_batch_state(1, 3, 1)
+        memo.set_window_cache(16)
+        for secs in lengths:
+            pcm = full[: secs * 16000]
+            plain.full_batch(fp, [pcm]); memo.full_batch(fp, [pcm])
+            a, b = plain.batch_segments(0), memo.batch_segments(0)
+            assert len(a) == len(b) and len(a) > 0
+            for x, y in zip(a, b):
+                assert (x.t0, x.t1, x.text, x.tokens) == (y.t0, y.t1, y.text, y.tokens), secs
+            assert plain.batch_n_fallbacks(0) == memo.batch_n_fallbacks(0)
+        stats = memo.window_cache_stats()
+        assert stats["stores"] >= 2 and stats["hits"] >= 4, stats       # windows 0 and 1 are interior from the second peek on
+        assert plain.window_cache_stats() == {"hits": 0, "stores": 0}
+        # a different recording never hits
+        other = synth_pcm(42, 71 * 16000)
+        h0 = memo.window_cache_stats()["hits"]
+        memo.full_batch(fp, [other])
+        assert memo.window_cache_stats()["hits"] == h0
+        memo.set_window_cache(0)
+        memo.full_batch(fp, [full[: 77 * 16000]])
+        assert memo.window_cache_stats()["hits"] == h0
+        plain.free(); memo.free()
+    ctx.free()
+
+
 def test_pipeline_groups_do_not_change_results(wr, model_path):
     """Decoding index ranges of the batch one after the other while the encoder stream still works on the later ones
     (wmi_set_pipeline_groups) changes which sequences share a decoder pass, never their tokens."""
