@@ -201,6 +201,9 @@ extern "C" {
     pub fn wmi_full_batch(ctx: *mut whisper_context, state: *mut whisper_state, params: whisper_full_params, samples: *const *const c_float,
                           n_samples: *const c_int, n_utts: c_int, samples_on_device: c_int) -> c_int;
     pub fn wmi_batch_n_segments(state: *mut whisper_state, utt: c_int) -> c_int;
+    /// Remember finished interior 30 s windows between calls (growing recordings: live coaching); 0 = off.
+    pub fn wmi_set_window_cache(state: *mut whisper_state, max_windows: c_int);
+    pub fn wmi_get_window_cache_stats(state: *mut whisper_state, hits: *mut i64, stores: *mut i64);
     pub fn wmi_batch_segment_text(state: *mut whisper_state, utt: c_int, seg: c_int) -> *const c_char;
 }
 
