@@ -77,6 +77,31 @@ def test_greedy_tokens_identical(wr, oracle, model_path, arch):
     assert all(same)          # contract: identical greedy sequences on >= 99 % of utterances
 
 
+def test_greedy_identical_rate_over_many_utterances(wr, oracle, model_path):
+    """The parity contract's rate -- greedy token sequences identical on >= 99 % of utterances -- over 160 seeded clips of
+    1.5 to 14 s in one ragged batch (timestamps on, text context carried), not just a handful."""
+    path = model_path("micro.en", decisive=4.0)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0)
+    fp.set_language("en")
+    rng = np.random.default_rng(123)
+    secs = rng.uniform(1.5, 14.0, size=160)
+    pcms = [synth_pcm(1000 + i, int(16000 * s)) for i, s in enumerate(secs)]
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    ctx = wr.WhisperContext(path); st = ctx.create_batch_state(len(pcms), 1, 16)
+    st.full_batch(fp, pcms)
+    op = _oracle_params(oracle, fp)
+    same, n_tok = 0, 0
+    for u, pcm in enumerate(pcms):
+        ref = ost.full(op, pcm)
+        same += _same(st.batch_segments(u), ref)
+        n_tok += sum(len(s["tokens"]) for s in ref)
+    st.free(); ctx.free(); ost.close(); om.close()
+    print("identical utterances:", same, "of", len(pcms), "| reference tokens:", n_tok)
+    assert n_tok > 1000
+    assert same >= 0.99 * len(pcms), (same, len(pcms))
+
+
 def test_greedy_default_params_with_fallback(wr, oracle, model_path):
     """Default whisper_full parameters. Random weights give low average log-probabilities, so every window walks the
     whole temperature ladder and the T>0 path (host-side draw with the decoder's mt19937 over the device-computed
