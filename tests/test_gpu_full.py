@@ -275,6 +275,34 @@ def test_window_memo_on_a_growing_recording(wr, model_path):
     ctx.free()
 
 
+def test_two_states_on_two_threads(wr, model_path):
+    """Handy calls the engine from whatever thread has work (tokio blocking tasks, the live-coaching thread; reference
+    transcription.rs:383, live_coaching.rs:70, discord_conversation.rs:475): two states of one context running at the
+    same time from two threads return what they return one after the other."""
+    import threading
+    ctx = wr.WhisperContext(model_path("mini", decisive=4.0))
+    fp = wr.FullParams(wr.SamplingStrategy.BeamSearch(3, -1.0)); fp.set_language("en")
+    sets = [[synth_pcm(60 + i, int(16000 * s)) for i, s in enumerate((9.0, 31.0, 4.5))],
+            [synth_pcm(70 + i, int(16000 * s)) for i, s in enumerate((20.0, 2.5, 12.0, 6.0))]]
+    states = [ctx.create_batch_state(4, 3, 2) for _ in sets]
+    def run(k):
+        states[k].full_batch(fp, sets[k])
+        return [[(s.t0, s.t1, s.text, tuple(s.tokens)) for s in states[k].batch_segments(u)] for u in range(len(sets[k]))]
+    serial = [run(0), run(1)]
+    for _ in range(3):
+        got = [None, None]; errs = []
+        def work(k):
+            try: got[k] = run(k)
+            except Exception as e: errs.append(e)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not errs, errs
+        assert got == serial
+    for st in states: st.free()
+    ctx.free()
+
+
 def test_pipeline_groups_do_not_change_results(wr, model_path):
     """Decoding index ranges of the batch one after the other while the encoder stream still works on the later ones
     (wmi_set_pipeline_groups) changes which sequences share a decoder pass, never their tokens."""
