@@ -9,7 +9,7 @@ Handy's Rust host reaches the engine as (reference: src-tauri/src/managers/trans
 and transcribe-rs implements those on whisper-rs' WhisperContext / WhisperState / FullParams.
 The Rust toolchain is not available in this build environment, so the same names, argument
 meaning and error behaviour are mirrored here for the parity tests and the benchmark; the Rust
-binding a maintainer would use is rust/whisper-rs-sys (see INTEGRATION.md).
+binding a maintainer would use is rust/whisper-rs-sys.
 
 There is no CPU fallback: if the shared library is missing or no HIP device is present, loading
 fails with an exception.

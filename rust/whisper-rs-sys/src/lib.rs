@@ -208,7 +208,7 @@ extern "C" {
 }
 
 /// whisper-rs installs a ggml log hook through this symbol; the engine has no ggml, so it is a no-op
-/// kept on the Rust side (the shared library must not export any `ggml_*` symbol).
+/// kept on the Rust side (the shared library must not export any `ggml_*` symbol: Handy already isolates llama.cpp in a sidecar because of ggml symbol clashes).
 #[no_mangle]
 pub unsafe extern "C" fn ggml_log_set(_log_callback: ggml_log_callback, _user_data: *mut c_void) {}
 
