@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("WMI_BENCH_BATCH", "256")), help="utterances per GPU per step")
     ap.add_argument("--tokens", type=int, default=128, help="decoded tokens per utterance")
     ap.add_argument("--arch", default="large-v3-turbo")
-    ap.add_argument("--enc-chunk", type=int, default=int(os.environ.get("WMI_ENC_CHUNK", "16")))
+    ap.add_argument("--enc-chunk", type=int, default=int(os.environ.get("WMI_ENC_CHUNK", "128")), help="utterances per encoder launch set")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WMI_BENCH_STREAMS", "1")),
                     help="engine states per GPU, each on its own HIP stream and host thread, each transcribing --batch utterances per step")
     ap.add_argument("--pipeline-groups", type=int, default=int(os.environ.get("WMI_PIPELINE_GROUPS", "1")),

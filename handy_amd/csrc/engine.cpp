@@ -48,7 +48,7 @@ constexpr size_t kSplitMaxRows = 1024;
 Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
     max_utts_ = std::max(1, max_utts);
     max_dec_ = std::min(8, std::max(1, max_dec));
-    enc_chunk_ = enc_chunk > 0 ? enc_chunk : 16;
+    enc_chunk_ = enc_chunk > 0 ? enc_chunk : 128;        // big chunks: fewer, fuller GEMM launches (about 70 MB of workspace per utterance)
     enc_chunk_ = std::min(enc_chunk_, max_utts_);
     d_ = m->hp.n_audio_state; H_ = m->hp.n_audio_head; Le_ = m->hp.n_audio_layer; Ld_ = m->hp.n_text_layer;
     T_full_ = m->hp.n_audio_ctx; n_mel_ = m->hp.n_mels; V_ = m->hp.n_vocab; Vp_ = m->n_vocab_pad;

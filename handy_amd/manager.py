@@ -159,7 +159,7 @@ class _HipBatchEngine:
 
     def __init__(self, path: str, gpu_device: int, max_batch: int):
         self.ctx = wr.WhisperContext(path, wr.WhisperContextParameters(gpu_device))
-        self.state = self.ctx.create_batch_state(max_batch, 5, min(16, max_batch))
+        self.state = self.ctx.create_batch_state(max_batch, 5, 0)
         self._proto = wr.WhisperEngine()
 
     def transcribe_batch(self, audios, params) -> List[str]:

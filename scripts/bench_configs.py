@@ -21,7 +21,7 @@ for name in which:
     t0 = time.time(); path = model_file(arch); t_model = time.time() - t0
     ctx = wr.WhisperContext(path)
     beam = 5 if mode == "beam5" else 1
-    st = ctx.create_batch_state(B, beam, min(16, B))
+    st = ctx.create_batch_state(B, beam, 0)
     st.set_force_tokens(tokens)
     fp = wr.FullParams(wr.SamplingStrategy.BeamSearch(5, -1.0) if beam > 1 else wr.SamplingStrategy.Greedy(1))
     fp.set_temperature_inc(0.0); fp.set_no_timestamps(True); fp.set_language("en")

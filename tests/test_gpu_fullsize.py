@@ -108,3 +108,24 @@ def test_turbo_batch_properties(wr, turbo_path):
         st1.full_batch(fp, [clips[c]])
         assert list(st1.batch_tokens(0)) == toks[first[c]], f"clip {c}: batch of one differs from the batch of {len(order)}"
     st1.free(); ctx.free()
+
+
+def test_turbo_encoder_chunk_size_does_not_change_results(wr, turbo_path):
+    """136 utterances encoded as one chunk of 136 (204 000 activation rows, the size the benchmark's default works at) and in
+    chunks of 16: identical tokens, and copies of a clip identical across the batch."""
+    ctx = wr.WhisperContext(turbo_path)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0); fp.set_no_timestamps(True); fp.set_language("en")
+    base = [synth_pcm(50 + i, int(16000 * s)) for i, s in enumerate((30.0, 30.0, 17.3, 30.0, 8.0, 30.0, 29.9, 30.0))]
+    pcms = [base[i % 8] for i in range(136)]
+    toks = {}
+    for E in (16, 136):
+        st = ctx.create_batch_state(len(pcms), 1, E)
+        st.set_force_tokens(10)
+        st.full_batch(fp, pcms)
+        toks[E] = [list(st.batch_tokens(u)) for u in range(len(pcms))]
+        st.free()
+    ctx.free()
+    assert toks[16] == toks[136]
+    for u in range(8, len(pcms)):
+        assert toks[136][u] == toks[136][u % 8]
