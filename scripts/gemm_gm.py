@@ -7,8 +7,8 @@ L = wr.load_library()
 L.wmi_bench_gemm.restype = C.c_int
 L.wmi_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
 L.wmi_debug_set_tile_group.argtypes = [C.c_int]
-for (M, N, K) in [(24000, 1280, 5120), (24000, 1280, 1280), (24000, 5120, 1280), (24000, 3840, 1280)]:
-    for gm in (3, 4, 5, 6, 7, 8, 12, 16):
+for (M, N, K) in [(int(sys.argv[1]) if len(sys.argv) > 1 else 24000, n, k) for (n, k) in ((1280, 5120), (1280, 1280), (5120, 1280), (3840, 1280))]:
+    for gm in (3, 4, 5, 6, 8, 12, 16, 32):
         L.wmi_debug_set_tile_group(gm)
         best = 1e9
         for rep in range(3):
