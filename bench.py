@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("WMI_BENCH_BATCH", "256")), help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("WMI_BENCH_BATCH", "1024")), help="utterances per GPU per step")
     ap.add_argument("--tokens", type=int, default=128, help="decoded tokens per utterance")
     ap.add_argument("--arch", default="large-v3-turbo")
     ap.add_argument("--enc-chunk", type=int, default=int(os.environ.get("WMI_ENC_CHUNK", "128")), help="utterances per encoder launch set")
