@@ -9,7 +9,7 @@ L.wmi_bench_gemm.restype = C.c_int
 L.wmi_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
 dev = torch.device("cuda", 0)
 out = []
-for (M, N, K) in [(24000, 5120, 1280), (24000, 1280, 5120), (24000, 3840, 1280), (24000, 1280, 1280)]:
+for (M, N, K) in [(int(sys.argv[1]) if len(sys.argv) > 1 else 24000, n, k) for (n, k) in ((5120, 1280), (1280, 5120), (3840, 1280), (1280, 1280))]:
     A = torch.randn(M, K, device=dev, dtype=torch.float16)
     W = torch.randn(N, K, device=dev, dtype=torch.float16)
     for _ in range(3):
