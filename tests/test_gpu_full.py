@@ -234,21 +234,21 @@ def test_batching_front_equals_one_call_at_a_time(wr, model_path):
     tm.unload_model()
 
 
-def test_window_memo_on_a_growing_recording(wr, model_path):
+@pytest.mark.parametrize("arch,lang", [("micro.en", "en"), ("micro", "auto")])
+def test_window_memo_on_a_growing_recording(wr, model_path, arch, lang):
     """Handy's live coaching transcribes the whole recording so far every few seconds (reference live_coaching.rs:84-97).
     With the window memo on, the interior 30 s windows of the earlier calls are taken over instead of being encoded and
     decoded again, and every call returns exactly what it returns with the memo off -- greedy with temperature fallback
     and beam search, text context carried between windows."""
-    path = model_path("micro.en")
+    path = model_path(arch)
     ctx = wr.WhisperContext(path)
-    rng = np.random.default_rng(9)
     full = synth_pcm(41, 100 * 16000)
     full[: 8 * 16000] *= 1.0
     full[8 * 16000:] *= 0.4                    # the loudest stretch is early: the utterance-wide log-mel maximum stops moving
     lengths = [40, 71, 74, 77, 100]             # seconds recorded at each peek
     for strategy in (wr.SamplingStrategy.Greedy(2), wr.SamplingStrategy.BeamSearch(3, -1.0)):
         fp = wr.FullParams(strategy)
-        fp.set_language("en")
+        fp.set_language(lang)                   # "auto": the first window is encoded for language detection on every call
         plain = ctx.create_batch_state(1, 3, 1)
         memo = ctx.create_batch_state(1, 3, 1)
         memo.set_window_cache(16)
@@ -261,7 +261,7 @@ def test_window_memo_on_a_growing_recording(wr, model_path):
                 assert (x.t0, x.t1, x.text, x.tokens) == (y.t0, y.t1, y.text, y.tokens), secs
             assert plain.batch_n_fallbacks(0) == memo.batch_n_fallbacks(0)
         stats = memo.window_cache_stats()
-        assert stats["stores"] >= 2 and stats["hits"] >= 4, stats       # windows 0 and 1 are interior from the second peek on
+        assert stats["stores"] >= 2 and stats["hits"] >= (4 if lang == "en" else 2), stats       # windows 0 and 1 are interior from the second peek on
         assert plain.window_cache_stats() == {"hits": 0, "stores": 0}
         # a different recording never hits
         other = synth_pcm(42, 71 * 16000)
