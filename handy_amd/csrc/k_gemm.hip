@@ -523,6 +523,7 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 27: return launch<256, 256, 2, 4, 2, EpiF16, kSpread | kFirstHalf | kBufferLoad>(A, lda, W, ldw, M, N, K, e, st);   // staging through buffer_load ... lds
         case 25: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kNoMfma | kSpread | kFirstHalf | kSameTile>(A, lda, W, ldw, M, N, K, e, st);   // loads only, all L2 hits
         case 26: return launch<256, 256, 2, 4, 2, EpiF16, kSpread | kFirstHalf | kSameTile>(A, lda, W, ldw, M, N, K, e, st);                          // full loop, all L2 hits
+        case 16: return launch<256, 256, 2, 4, 2, EpiF16, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, (const float *)W, 1, 1.0f}, st);   // shipped kernel with the bias + GELU epilogue (bias values arbitrary)
         case 11: return launch<256, 256, 2, 4, 2, EpiF16, 1>(A, lda, W, ldw, M, N, K, e, st);   // no global loads in the loop
         case 12: return launch<256, 256, 2, 4, 2, EpiF16, 3>(A, lda, W, ldw, M, N, K, e, st);   // no global loads, no LDS reads
         case 13: return launch<256, 256, 2, 4, 2, EpiF16, 4>(A, lda, W, ldw, M, N, K, e, st);   // no MFMA

@@ -5,8 +5,9 @@ from handy_amd import whisper_rs as wr
 L = wr.load_library()
 L.wmi_bench_gemm.restype = C.c_int
 L.wmi_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
-names = {0: "256x128 8w 3st", 1: "256x256 8w 2st", 2: "128x128 4w 3st", 3: "128x128 4w 2st", 4: "256x128 8w 2st", 5: "128x256 8w 3st", 6: "64x64 4w 4st", 7: "128x64 4w 4st", 9: "256x256 spread-dma", 10: "256x128 3st spread", 11: "256x256 no-gload", 12: "256x256 mfma-only", 13: "256x256 no-mfma", 14: "stamped", 15: "256x256 spread first half (shipped)", 22: "loads + MFMA (no LDS reads)", 23: "LDS reads only", 24: "loads only", 25: "loads only, same tile", 26: "full loop, same tile", 27: "buffer_load lds staging"}
-shapes = [(24000, 5120, 1280), (24000, 1280, 5120), (24000, 3840, 1280), (24000, 1280, 1280)]
+names = {0: "256x128 8w 3st", 1: "256x256 8w 2st", 2: "128x128 4w 3st", 3: "128x128 4w 2st", 4: "256x128 8w 2st", 5: "128x256 8w 3st", 6: "64x64 4w 4st", 7: "128x64 4w 4st", 9: "256x256 spread-dma", 10: "256x128 3st spread", 11: "256x256 no-gload", 12: "256x256 mfma-only", 13: "256x256 no-mfma", 14: "stamped", 15: "256x256 spread first half (shipped)", 22: "loads + MFMA (no LDS reads)", 23: "LDS reads only", 24: "loads only", 25: "loads only, same tile", 26: "full loop, same tile", 27: "buffer_load lds staging", 16: "shipped, bias + GELU epilogue"}
+MROWS = int(os.environ.get('WMI_SWEEP_ROWS', '24000'))
+shapes = [(MROWS, 5120, 1280), (MROWS, 1280, 5120), (MROWS, 3840, 1280), (MROWS, 1280, 1280)]
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 9, 15]
 L.wmi_debug_gemm_variant_diff.restype = C.c_int
 L.wmi_debug_gemm_variant_diff.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
