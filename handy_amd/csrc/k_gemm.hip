@@ -33,6 +33,35 @@ __device__ __forceinline__ float gelu_f16_dev(float x) {
     return x >= 10.0f ? x : (x <= -10.0f ? 0.0f : g);
 }
 
+// The same GELU for the four values of a lane at once, on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32) and straight to
+// f16: every value goes through the same operations in the same order as in gelu_f16_dev (the products, the fused
+// 1 + m*h and h - h*r, one rounding to f16), so the bits are the same; it is about a third fewer instructions, and the
+// fc1 epilogue is bound by their number.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x4 gelu_f16_dev4(f32x4 x) {
+    const f16x4 h16 = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
+    f16x4 out;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const f32x2 h = {(float)h16[2 * p], (float)h16[2 * p + 1]};
+        const f32x2 a = 0.79788456080286535587989211986876f * h;
+        const f32x2 m = 0.044715f * h;
+        const f32x2 t = __builtin_elementwise_fma(m, h, f32x2{1.0f, 1.0f});
+        const f32x2 u = (a * t) * 2.8853900817779268f;
+        const f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+        const f32x2 d = e + 1.0f;
+        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const f32x2 g = __builtin_elementwise_fma(-r, h, h);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float xv = x[2 * p + q];
+            const f16 gv = (f16)g[q];
+            out[2 * p + q] = xv >= 10.0f ? h16[2 * p + q] : (xv <= -10.0f ? (f16)0.0f : gv);
+        }
+    }
+    return out;
+}
+
 // ------------------------------------------------------------------------------------------ epilogues
 // Each epilogue receives one lane's 4 accumulators: row m, columns n..n+3 (n % 4 == 0).
 
@@ -46,7 +75,7 @@ struct EpiF16 {            // out[m][n] = f16(act((acc + bias) * scale))
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         if (bias) { const f32x4 b = *(const f32x4 *)(bias + n); a += b; }
         a *= scale;
-        if (gelu) { a[0] = gelu_f16_dev(a[0]); a[1] = gelu_f16_dev(a[1]); a[2] = gelu_f16_dev(a[2]); a[3] = gelu_f16_dev(a[3]); }
+        if (gelu) return gelu_f16_dev4(a);
         return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
     __device__ __forceinline__ bool wide(int n) const { return true; }
