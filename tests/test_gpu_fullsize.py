@@ -78,6 +78,18 @@ def test_turbo_greedy_tokens_match_oracle(wr, oracle, turbo_path):
     assert _same(got[0], ref[0])
 
 
+def test_turbo_beam_search_matches_oracle(wr, oracle, turbo_path):
+    """Beam search (3 beams, deterministic top-k candidates, the MFMA group cross-attention and the transposed V copy) on
+    two clips in one batch against the oracle: token ids, segment times and text."""
+    from test_gpu_full import _run_pair, _same
+    fp = wr.FullParams(wr.SamplingStrategy.BeamSearch(3, -1.0))
+    fp.set_temperature_inc(0.0); fp.set_language("en")
+    pcms = [synth_pcm(33, int(11.0 * 16000)), synth_pcm(34, 30 * 16000)]
+    got, ref, _ = _run_pair(wr, oracle, turbo_path, fp, pcms, max_dec=3, beam_candidates_topk=1, force_n_tokens=10)
+    for u in range(len(pcms)):
+        assert _same(got[u], ref[u]), (u, [g.tokens for g in got[u]], [r["tokens"] for r in ref[u]])
+
+
 def test_turbo_batch_properties(wr, turbo_path):
     ctx = wr.WhisperContext(turbo_path)
     n_force = 24
