@@ -141,3 +141,17 @@ def test_turbo_encoder_chunk_size_does_not_change_results(wr, turbo_path):
     assert toks[16] == toks[136]
     for u in range(8, len(pcms)):
         assert toks[136][u] == toks[136][u % 8]
+
+
+def test_large_v3_beam5_matches_oracle(wr, oracle, tmp_path_factory):
+    """Whisper large-v3 dimensions (32 encoder + 32 decoder layers, 128 mels), beam size 5 -- the decoder KV-cache and beam
+    path at its real depth -- on one clip against the oracle."""
+    from handy_amd import ggml_file as gf
+    from test_gpu_full import _run_pair, _same
+    path = str(tmp_path_factory.mktemp("v3") / "synthetic-large-v3.bin")
+    gf.write_synthetic_model(path, "large-v3", seed=1, decisive=2.0)
+    fp = wr.FullParams(wr.SamplingStrategy.BeamSearch(5, -1.0))
+    fp.set_temperature_inc(0.0); fp.set_language("en")
+    pcms = [synth_pcm(35, int(21.0 * 16000))]
+    got, ref, _ = _run_pair(wr, oracle, path, fp, pcms, max_dec=5, beam_candidates_topk=1, force_n_tokens=8)
+    assert _same(got[0], ref[0]), ([g.tokens for g in got[0]], [r["tokens"] for r in ref[0]])
