@@ -155,3 +155,20 @@ def test_large_v3_beam5_matches_oracle(wr, oracle, tmp_path_factory):
     pcms = [synth_pcm(35, int(21.0 * 16000))]
     got, ref, _ = _run_pair(wr, oracle, path, fp, pcms, max_dec=5, beam_candidates_topk=1, force_n_tokens=8)
     assert _same(got[0], ref[0]), ([g.tokens for g in got[0]], [r["tokens"] for r in ref[0]])
+
+
+@pytest.mark.parametrize("arch", ["small", "tiny.en"])
+def test_small_models_greedy_batch_matches_oracle(wr, oracle, tmp_path_factory, arch):
+    """Whisper small (d = 768, 12 + 12 layers, multilingual vocabulary) and tiny.en (d = 384, 4 + 4 layers, 6 heads, English-only
+    vocabulary) at their real dimensions: a ragged batch, greedy with timestamps, against the oracle -- the split-K decoder
+    GEMMs at the widths only these sizes have."""
+    from handy_amd import ggml_file as gf
+    from test_gpu_full import _run_pair, _same
+    path = str(tmp_path_factory.mktemp("m") / f"synthetic-{arch}.bin")
+    gf.write_synthetic_model(path, arch, seed=2, decisive=2.0)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0); fp.set_language("en")
+    pcms = [synth_pcm(36 + i, int(s * 16000)) for i, s in enumerate((30.0, 6.5, 18.0, 41.0))]
+    got, ref, _ = _run_pair(wr, oracle, path, fp, pcms, max_dec=1, force_n_tokens=14)
+    for u in range(len(pcms)):
+        assert _same(got[u], ref[u]), (u, [g.tokens for g in got[u]], [r["tokens"] for r in ref[u]])
