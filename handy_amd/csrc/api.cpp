@@ -408,6 +408,22 @@ int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C
     WMI_CATCH(-1)
 }
 
+int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_blocks, unsigned short *out) {
+    WMI_TRY
+    const int bb = wmi::quant_block_bytes(ggml_type);
+    if (!bb || n_blocks <= 0 || !blocks || !out) return -1;
+    void *db = nullptr; f16 *dout = nullptr;
+    int rc = -1;
+    if (hipMalloc(&db, (size_t)n_blocks * bb + 256) == hipSuccess && hipMalloc(&dout, (size_t)n_blocks * 64 + 256) == hipSuccess &&
+        hipMemcpy(db, blocks, (size_t)n_blocks * bb, hipMemcpyHostToDevice) == hipSuccess &&
+        wmi::expand_blocks_f16(db, ggml_type, (long)n_blocks, dout, nullptr) && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(out, dout, (size_t)n_blocks * 64, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = 0;
+    (void)hipFree(db); (void)hipFree(dout);
+    return rc;
+    WMI_CATCH(-1)
+}
+
 int wmi_debug_read_gemm_stamps(unsigned long long *out, int n) { return wmi::gemm_read_stamps(out, n) ? 0 : -1; }
 void wmi_debug_set_tile_group(int rows) { if (rows >= 1) wmi::g_tile_group_rows = rows; }
 

@@ -23,6 +23,11 @@ extern int g_tile_group_rows;
 bool gemm_read_stamps(unsigned long long *out, int n);
 bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, hipStream_t st);
 
+// ---- k_load.hip : load-time expansion of block-quantised tensors ------------------------------
+int quant_block_bytes(int ttype);                          // bytes per 32-weight block of a ggml block type, 0 if not one
+// blocks (device, 2-byte aligned) of ggml type `ttype` -> dst[n_blocks * 32] fp16 (device, 16-byte aligned)
+bool expand_blocks_f16(const void *blocks, int ttype, long n_blocks, f16 *dst, hipStream_t st);
+
 // ---- k_mel.hip : log-mel frontend -----------------------------------------------------------
 struct MelTables {           // device-resident constants of one model
     const float *filters;    // [n_mel][201] dense table from the model file

@@ -1,6 +1,7 @@
 // ggml Whisper file -> device tensors. The container layout is the legacy ggml ".bin" format of the
 // files Handy's catalog downloads (reference: src-tauri/src/managers/model.rs:71-146: f16, Q4_1 and
-// Q5_0 variants). Quantised tensors are expanded to fp16 once, here, at load time.
+// Q5_0 variants). Quantised tensors are expanded to fp16 once, at load time: the large matrices on the device from
+// their uploaded blocks (k_load.hip), the few small vectors on the host.
 #include "model.h"
 
 #include <math.h>
@@ -109,6 +110,43 @@ struct Uploader {
         if (n_alloc > n && hipMemset(d, 0, n_alloc * sizeof(T) + 256) != hipSuccess) ok = false;
         if (n && hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) ok = false;
         return (T *)d;
+    }
+
+    // fp16 matrices are assembled on the device: f16 tensors go up straight from the file image, block-quantised ones
+    // go up as blocks into a staging buffer and are expanded there.
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    f16 *alloc_f16(size_t n, size_t n_alloc = 0) {
+        if (n_alloc < n) n_alloc = n;
+        void *d = nullptr;
+        if (hipMalloc(&d, n_alloc * sizeof(f16) + 256) != hipSuccess) { ok = false; log_msg(2, "load: hipMalloc of %zu bytes failed\n", n_alloc * sizeof(f16)); return nullptr; }
+        m->allocs.push_back(d); m->bytes += n_alloc * sizeof(f16);
+        if (n_alloc > n && hipMemset(d, 0, n_alloc * sizeof(f16) + 256) != hipSuccess) ok = false;
+        return (f16 *)d;
+    }
+    void fill_f16(const TensorRef &t, f16 *dst) {
+        if (!dst || !ok) return;
+        if (t.ttype == 1) { if (hipMemcpy(dst, t.data, t.n * 2, hipMemcpyHostToDevice) != hipSuccess) ok = false; return; }
+        if (t.ttype == 0) {
+            std::vector<f16> v(t.n);
+            const float *s = (const float *)t.data;
+            for (size_t i = 0; i < t.n; i++) { float x; memcpy(&x, s + i, 4); v[i] = (f16)x; }
+            if (hipMemcpy(dst, v.data(), t.n * 2, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+            return;
+        }
+        const size_t nb = t.n / 32, bytes = nb * (size_t)quant_block_bytes(t.ttype);
+        if (bytes > stage_bytes) {
+            if (stage) { (void)hipDeviceSynchronize(); (void)hipFree(stage); stage = nullptr; stage_bytes = 0; }
+            if (hipMalloc(&stage, bytes + 256) != hipSuccess) { ok = false; log_msg(2, "load: hipMalloc of %zu staging bytes failed\n", bytes); return; }
+            stage_bytes = bytes;
+        }
+        // the copy and the kernel both run on the null stream: the next tensor's copy waits for this one's expansion
+        if (hipMemcpy(stage, t.data, bytes, hipMemcpyHostToDevice) != hipSuccess || !expand_blocks_f16(stage, t.ttype, (long)nb, dst, nullptr)) ok = false;
+    }
+    bool finish() {
+        if (hipDeviceSynchronize() != hipSuccess) ok = false;
+        if (stage) { (void)hipFree(stage); stage = nullptr; stage_bytes = 0; }
+        return ok;
     }
 };
 
@@ -220,16 +258,12 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
         if (const TensorRef *t = need(name, n)) expand_f32(*t, v.data());
         return v;
     };
-    auto f16_into = [&](const std::string &name, size_t n, f16 *dst) {      // f16 tensors are copied bit-for-bit
-        const TensorRef *t = need(name, n);
-        if (!t) return;
-        if (t->ttype == 1) { memcpy(dst, t->data, n * 2); return; }
-        std::vector<float> v(n); expand_f32(*t, v.data());
-        for (size_t i = 0; i < n; i++) dst[i] = (f16)v[i];
-    };
 
     if (hipSetDevice(device) != hipSuccess) { log_msg(2, "load: cannot select HIP device %d\n", device); return nullptr; }
     Uploader U{M.get()};
+    auto f16_into = [&](const std::string &name, size_t n, f16 *dev) {      // f16 tensors are copied bit-for-bit
+        if (const TensorRef *t = need(name, n)) U.fill_f16(*t, dev);
+    };
     const size_t dd = (size_t)d * d;
     {   // mel tables
         std::vector<int> lo(n_mel, 0), hi(n_mel, 0);
@@ -279,11 +313,11 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
         M->ln_post_w = U.put(lw.data(), lw.size()); M->ln_post_b = U.put(lb.data(), lb.size());
     }
     auto put_f32 = [&](const std::string &name, size_t n) { auto v = f32v(name, n); return U.put(v.data(), v.size()); };
-    auto put_f16 = [&](const std::string &name, size_t n) { std::vector<f16> v(n); f16_into(name, n, v.data()); return U.put(v.data(), v.size()); };
+    auto put_f16 = [&](const std::string &name, size_t n) { f16 *v = U.alloc_f16(n); f16_into(name, n, v); return v; };
     auto put_qkv = [&](const std::string &pre, f16 **w, float **b) {
-        std::vector<f16> v(3 * dd);
-        f16_into(pre + "query.weight", dd, v.data()); f16_into(pre + "key.weight", dd, v.data() + dd); f16_into(pre + "value.weight", dd, v.data() + 2 * dd);
-        *w = U.put(v.data(), v.size());
+        f16 *v = U.alloc_f16(3 * dd);
+        if (v) { f16_into(pre + "query.weight", dd, v); f16_into(pre + "key.weight", dd, v + dd); f16_into(pre + "value.weight", dd, v + 2 * dd); }
+        *w = v;
         std::vector<float> bb(3 * (size_t)d, 0.0f);
         auto q = f32v(pre + "query.bias", d), vv = f32v(pre + "value.bias", d);
         std::copy(q.begin(), q.end(), bb.begin()); std::copy(vv.begin(), vv.end(), bb.begin() + 2 * d);
@@ -302,7 +336,7 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
     }
     M->dec.resize(hp.n_text_layer);
     {
-        std::vector<f16> xkv((size_t)hp.n_text_layer * 2 * dd);
+        f16 *xkv = U.alloc_f16((size_t)hp.n_text_layer * 2 * dd);
         std::vector<float> xkvb((size_t)hp.n_text_layer * 2 * d, 0.0f);
         for (int i = 0; i < hp.n_text_layer && !missing; i++) {
             DecLayer &D = M->dec[i];
@@ -316,19 +350,20 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
             D.ln2_w = put_f32(p + "mlp_ln.weight", d); D.ln2_b = put_f32(p + "mlp_ln.bias", d);
             D.fc1 = put_f16(p + "mlp.0.weight", 4 * dd); D.b1 = put_f32(p + "mlp.0.bias", 4 * (size_t)d);
             D.fc2 = put_f16(p + "mlp.2.weight", 4 * dd); D.b2 = put_f32(p + "mlp.2.bias", d);
-            f16_into(p + "cross_attn.key.weight", dd, xkv.data() + (size_t)(2 * i) * dd);
-            f16_into(p + "cross_attn.value.weight", dd, xkv.data() + (size_t)(2 * i + 1) * dd);
+            if (xkv) {
+                f16_into(p + "cross_attn.key.weight", dd, xkv + (size_t)(2 * i) * dd);
+                f16_into(p + "cross_attn.value.weight", dd, xkv + (size_t)(2 * i + 1) * dd);
+            }
             auto vb = f32v(p + "cross_attn.value.bias", d);
             std::copy(vb.begin(), vb.end(), xkvb.begin() + (size_t)(2 * i + 1) * d);
         }
-        M->xkv_w = U.put(xkv.data(), xkv.size());
+        M->xkv_w = xkv;
         M->xkv_b = U.put(xkvb.data(), xkvb.size());
     }
     {
         M->n_vocab_pad = round_up(hp.n_vocab, 128);
-        std::vector<f16> te((size_t)hp.n_vocab * d);
-        f16_into("decoder.token_embedding.weight", te.size(), te.data());
-        M->d_te = U.put(te.data(), te.size(), (size_t)M->n_vocab_pad * d);
+        M->d_te = U.alloc_f16((size_t)hp.n_vocab * d, (size_t)M->n_vocab_pad * d);      // rows past n_vocab stay zero
+        f16_into("decoder.token_embedding.weight", (size_t)hp.n_vocab * d, M->d_te);
         M->d_pe = put_f32("decoder.positional_embedding", (size_t)hp.n_text_ctx * d);
         M->d_ln_w = put_f32("decoder.ln.weight", d); M->d_ln_b = put_f32("decoder.ln.bias", d);
     }
@@ -339,7 +374,7 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
         mark(" -"); mark(" '");
         M->nst_bitmap = U.put(bm.data(), bm.size());
     }
-    if (missing || !U.ok) return nullptr;
+    if (!U.finish() || missing) return nullptr;
     switch (hp.n_audio_layer) {
         case 4: M->type_name = "tiny"; break; case 6: M->type_name = "base"; break; case 12: M->type_name = "small"; break;
         case 24: M->type_name = "medium"; break; case 32: M->type_name = "large"; break; default: M->type_name = "custom"; break;

@@ -74,6 +74,10 @@ WHISPER_API int wmi_get_cross_kv(struct whisper_state *state, int layer, float *
 WHISPER_API int wmi_decode_logits_all(struct whisper_context *ctx, struct whisper_state *state, const whisper_token *tokens, int n_tokens, int n_past, float *logits_out);
 WHISPER_API int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C);          /* C = f16(A) f16(W)^T on the device */
 
+/* The loader's device-side expansion of ggml block-quantised tensors (types 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0; 32 weights a
+ * block) on host buffers: blocks -> out[n_blocks * 32] as fp16 bit patterns. */
+WHISPER_API int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_blocks, unsigned short *out);
+
 WHISPER_API int wmi_debug_read_gemm_stamps(unsigned long long *out, int n);                             /* harness: per-section cycle sums of variant 14 */
 WHISPER_API void wmi_debug_set_tile_group(int rows);                                                    /* harness knob: tile rows per L2 group */
 WHISPER_API int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_variant, float *max_abs_diff); /* harness */

@@ -32,6 +32,35 @@ def test_gemm_matches_numpy(wr, M, N, K):
     assert err <= 2e-3 * max(1.0, np.abs(ref).max()), err
 
 
+@pytest.mark.parametrize("name", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0"])
+def test_block_expansion_is_bit_exact(wr, name):
+    """The loader's device-side expansion of ggml block formats against the numpy expansion of the same bytes: identical
+    fp16 bit patterns, on quantised data and on arbitrary block bytes (every nibble, high bit and sign pattern)."""
+    import ctypes as C
+    from handy_amd import ggml_file as gf
+    tt = getattr(gf, "T_" + name)
+    L = wr.load_library()
+    rng = np.random.default_rng(tt)
+    n_blocks = 70001                                                   # not a multiple of the kernel's 256 blocks per workgroup
+    x = (rng.standard_normal(n_blocks * 32) * rng.choice([1e-3, 0.05, 3.0], n_blocks).repeat(32)).astype(np.float32)
+    raws = [gf.quantize(x, tt)]
+    bb = gf.TTYPE_BLOCK_BYTES[tt]
+    noise = rng.integers(0, 256, (n_blocks, bb), dtype=np.uint8)
+    scale = (rng.standard_normal((n_blocks, 2)) * 0.1).astype(np.float16)        # finite scales (and minimums), random quants
+    noise[:, 0:2] = scale[:, 0:1].view(np.uint8)
+    if name in ("Q4_1", "Q5_1"):
+        noise[:, 2:4] = scale[:, 1:2].view(np.uint8)
+    raws.append(noise.tobytes())
+    for raw in raws:
+        ref = gf.dequantize(raw, tt, n_blocks * 32).astype(np.float16)
+        out = np.empty(n_blocks * 32, np.uint16)
+        buf = np.frombuffer(raw, np.uint8)
+        assert L.wmi_debug_expand_blocks(tt, buf.ctypes.data_as(C.c_void_p), n_blocks, out.ctypes.data_as(C.c_void_p)) == 0
+        bad = np.flatnonzero(out != ref.view(np.uint16))
+        assert bad.size == 0, (name, bad.size, [hex(v) for v in out[bad[:6]]], [hex(v) for v in ref.view(np.uint16)[bad[:6]]], np.frombuffer(raw, np.uint8).reshape(n_blocks, bb)[bad[0] // 32][:2], bad[:6] % 32)
+    assert L.wmi_debug_expand_blocks(5, buf.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)) == -1   # not a block type
+
+
 @pytest.mark.parametrize("arch,n_mels", [("micro.en", 80), ("micro-v3", 128)])
 def test_mel_parity(wr, oracle, golden, model_path, arch, n_mels):
     path = model_path(arch)
