@@ -459,6 +459,36 @@ int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {
     WMI_CATCH(-1)
 }
 
+// LayerNorm harness: `iters` launches of one variant over M rows of width d (fp32 in, fp16 out), average ms by HIP events.
+int wmi_bench_layer_norm(int M, int d, int variant, int iters, float *ms_out) {
+    WMI_TRY
+    if (M <= 0 || d <= 0 || d % 4 || d > 1280 || iters <= 0 || !ms_out) return -1;
+    std::vector<float> hx((size_t)1 << 20), hw(d, 1.0f), hb(d, 0.5f);
+    uint32_t r = 99u;
+    for (auto &v : hx) { r = r * 1664525u + 1013904223u; v = (float)((int)(r >> 9) % 2001 - 1000) * 1e-3f; }
+    float *dx = nullptr, *dw = nullptr, *db = nullptr; f16 *dy = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    const size_t n = (size_t)M * d;
+    if (hipMalloc(&dx, n * 4 + 4096) == hipSuccess && hipMalloc(&dy, n * 2 + 4096) == hipSuccess && hipMalloc(&dw, d * 4) == hipSuccess && hipMalloc(&db, d * 4) == hipSuccess &&
+        hipMemcpy(dw, hw.data(), d * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(db, hb.data(), d * 4, hipMemcpyHostToDevice) == hipSuccess &&
+        hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        bool ok = true;
+        for (size_t o = 0; o < n && ok; o += hx.size()) ok = hipMemcpy(dx + o, hx.data(), std::min(hx.size(), n - o) * 4, hipMemcpyHostToDevice) == hipSuccess;
+        for (int i = 0; i < 2 && ok; i++) ok = wmi::layer_norm_variant(variant, dx, dw, db, dy, M, d, nullptr);
+        ok = ok && hipDeviceSynchronize() == hipSuccess && hipEventRecord(e0, nullptr) == hipSuccess;
+        for (int i = 0; i < iters && ok; i++) ok = wmi::layer_norm_variant(variant, dx, dw, db, dy, M, d, nullptr);
+        ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+        float ms = 0;
+        if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { *ms_out = ms / iters; rc = 0; }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(db);
+    return rc;
+    WMI_CATCH(-1)
+}
+
 // Harness: the same random operands through two tile variants; returns the largest |difference| of the fp16 outputs.
 int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_variant, float *max_abs_diff) {
     WMI_TRY
