@@ -283,7 +283,7 @@ __device__ __forceinline__ void write_tile(const Epi &epi, f32x4 (&acc)[TN][TM],
 // 8-lane write groups and the 16-lane read groups), and is then stored to memory as whole rows: one wave
 // instruction = 2 rows x 512 contiguous bytes. Direct stores from the accumulator layout touch 32 bytes per
 // row and instruction, which the memory side counts (and moves) as half-used 64-byte requests.
-template <class Epi>
+template <class Epi, int XB = 0>          // XB (harness): 1 = no global stores, 2 = no LDS round trip (stores of the raw pairs, wrong values)
 __device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, int wr, int wc, int wave, int lane, char *smem) {
     const int fr = lane & 15, fq = lane >> 4;
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): my last fragment reads are done
@@ -301,14 +301,17 @@ __device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4
             union { f16x8 h; unsigned u[4]; } o;
             o.u[0] = s0[0]; o.u[1] = s1[0]; o.u[2] = s0[1]; o.u[3] = s1[1];
             const int row = (fq & 1) ? ry : rx, chunk = (cn >> 3) + (fq >> 1);
-            *(f16x8 *)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = o.h;
+            if (XB & 2) { const int p = i * 4 + j / 2, r2 = p * 16 + wave * 2 + (lane >> 5); if (m0 + r2 < M) epi.store8(m0 + r2, n0 + (lane & 31) * 8, o.h); }
+            else *(f16x8 *)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = o.h;
         }
+    if (XB & 2) return;
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 16; p++) {
         const int row = p * 16 + wave * 2 + (lane >> 5), chunk = lane & 31;
         const f16x8 v = *(const f16x8 *)(smem + row * 512 + ((chunk ^ (row & 7)) << 4));
-        if (m0 + row < M) epi.store8(m0 + row, n0 + chunk * 8, v);
+        if (XB & 1) asm volatile("" ::"v"(v));
+        else if (m0 + row < M) epi.store8(m0 + row, n0 + chunk * 8, v);
     }
 }
 
@@ -480,19 +483,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
         if (ABL & 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); t_comp += t - t_prev; t_prev = t; }
     }
     if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && Epi::kWide) {
-        if (epi.wide_block(n0, BN)) write_tile_staged(epi, acc, M, m0, n0, wr, wc, wave, lane, smem);
+        if (epi.wide_block(n0, BN)) write_tile_staged<Epi, (ABL >> 8) & 3>(epi, acc, M, m0, n0, wr, wc, wave, lane, smem);
         else write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
     } else if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && !is_splitk<Epi>::value) {
         write_tile_staged_f32(epi, acc, M, m0, n0, wr, wc, wave, lane, smem);
     } else {
         write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
     }
-    if ((ABL & 16) && blockIdx.x < 2048) {
+    if ((ABL & 16) && (int)blockIdx.x >= max(0, (int)gridDim.x - 2048)) {       // the last 2048 workgroups: the steady state of a long launch
         const unsigned long long t_issue = __builtin_amdgcn_s_memtime();
         wait_vmcnt<0>();
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
-            unsigned long long *o = g_gemm_stamps + ((long)blockIdx.x * 8 + (wave & 7)) * 8;
+            unsigned long long *o = g_gemm_stamps + ((long)((int)blockIdx.x - max(0, (int)gridDim.x - 2048)) * 8 + (wave & 7)) * 8;
             o[0] = t_wait; o[1] = t_bar; o[2] = t_comp; o[3] = nk; o[4] = t_start; o[5] = t_pro; o[6] = t_issue - t_prev; o[7] = t_end;
         }
     }
@@ -544,6 +547,9 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 10: return launch<256, 128, 4, 2, 3, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);
         case 15: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 32>(A, lda, W, ldw, M, N, K, e, st);
         case 14: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16>(A, lda, W, ldw, M, N, K, e, st);   // with per-section cycle stamps
+        case 40: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32>(A, lda, W, ldw, M, N, K, e, st);         // stamps on the shipped schedule
+        case 41: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32 + 256>(A, lda, W, ldw, M, N, K, e, st);   // ... epilogue without global stores
+        case 42: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32 + 512>(A, lda, W, ldw, M, N, K, e, st);   // ... epilogue without the LDS round trip
         case 31: return launch<256, 256, 2, 4, 2, EpiResidual, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);   // fp32 read-modify-write epilogue (out must hold M x N floats; bias aliased, values irrelevant)
         case 30: return gemm_splitk(A, lda, W, ldw, M, N, K, gemm_pick_splits(N, K), (float *)out, st);   // the decoder's skinny path (out must hold the partials)
         case 22: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, e, st);   // loads + MFMA, fragments read once

@@ -8,10 +8,11 @@ L.wmi_bench_gemm.restype = C.c_int
 L.wmi_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
 L.wmi_debug_read_gemm_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 NB = 2048
+VARIANT = int(os.environ.get("WMI_STAMP_VARIANT", "14"))
 shapes = [tuple(int(x) for x in a.split('x')) for a in sys.argv[1:]] or [(24000, 1280, 5120), (24000, 5120, 1280), (24000, 3840, 1280)]
 for (M, N, K) in shapes:
     ms = C.c_float()
-    L.wmi_bench_gemm(M, N, K, 14, 3, C.byref(ms))
+    L.wmi_bench_gemm(M, N, K, VARIANT, 3, C.byref(ms))
     buf = (C.c_ulonglong * (NB * 64))()
     L.wmi_debug_read_gemm_stamps(buf, NB * 64)
     nblk = min(NB, ((M + 255) // 256) * (N // 256))
