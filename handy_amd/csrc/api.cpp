@@ -408,6 +408,29 @@ int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C
     WMI_CATCH(-1)
 }
 
+// out = f16(gelu(f16(A) f16(W)^T + bias)) through the fused GEMM epilogue, as fp16 bit patterns
+int wmi_debug_gemm_gelu(int M, int N, int K, const float *A, const float *W, const float *bias, unsigned short *out) {
+    WMI_TRY
+    if (M <= 0 || N % 64 || K % 64 || !A || !W || !out) return -1;
+    const int Mp = round_up(M, 256);
+    std::vector<f16> a((size_t)Mp * K, (f16)0.0f), w((size_t)N * K);
+    for (size_t i = 0; i < (size_t)M * K; i++) a[i] = (f16)A[i];
+    for (size_t i = 0; i < (size_t)N * K; i++) w[i] = (f16)W[i];
+    std::vector<float> hb(N, 0.0f);
+    if (bias) memcpy(hb.data(), bias, sizeof(float) * N);
+    f16 *da = nullptr, *dw = nullptr, *dc = nullptr; float *db = nullptr;
+    int rc = -1;
+    if (hipMalloc(&da, a.size() * 2) == hipSuccess && hipMalloc(&dw, w.size() * 2) == hipSuccess && hipMalloc(&dc, (size_t)Mp * N * 2) == hipSuccess && hipMalloc(&db, N * 4) == hipSuccess &&
+        hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice) == hipSuccess &&
+        gemm_f16(da, K, dw, K, M, N, K, dc, N, db, 1, 1.0f, nullptr) && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(out, dc, (size_t)M * N * 2, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = 0;
+    (void)hipFree(da); (void)hipFree(dw); (void)hipFree(dc); (void)hipFree(db);
+    return rc;
+    WMI_CATCH(-1)
+}
+
 int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_blocks, unsigned short *out) {
     WMI_TRY
     const int bb = wmi::quant_block_bytes(ggml_type);

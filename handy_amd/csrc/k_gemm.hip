@@ -35,8 +35,9 @@ __device__ __forceinline__ float gelu_f16_dev(float x) {
 
 // The same GELU for the four values of a lane at once, on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32) and straight to
 // f16: every value goes through the same operations in the same order as in gelu_f16_dev (the products, the fused
-// 1 + m*h and h - h*r, one rounding to f16), so the bits are the same; it is about a third fewer instructions, and the
-// fc1 epilogue is bound by their number.
+// 1 + m*h and h - h*r, one rounding to f16), so the bits are the same; it is about half the instructions, and the
+// fc1 epilogue is bound by their number (two transcendentals and ~10 other operations per value, 128 values per lane
+// and tile).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f16x4 gelu_f16_dev4(f32x4 x) {
     const f16x4 h16 = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
@@ -52,12 +53,11 @@ __device__ __forceinline__ f16x4 gelu_f16_dev4(f32x4 x) {
         const f32x2 d = e + 1.0f;
         const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
         const f32x2 g = __builtin_elementwise_fma(-r, h, h);
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const float xv = x[2 * p + q];
-            const f16 gv = (f16)g[q];
-            out[2 * p + q] = xv >= 10.0f ? h16[2 * p + q] : (xv <= -10.0f ? (f16)0.0f : gv);
-        }
+        // No guards here: for h >= 10 the reciprocal is below 2^-125 and h - h*r rounds to h, for h <= -10 exp(2u) is below
+        // 2^-125, r is exactly 1 and h - h is +0 -- the values the guarded scalar form returns. (The two differ for
+        // infinite inputs only, NaN here; an infinite activation turns into NaN in the next LayerNorm either way.)
+        out[2 * p] = (f16)g[0];
+        out[2 * p + 1] = (f16)g[1];
     }
     return out;
 }
@@ -548,6 +548,8 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 15: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 32>(A, lda, W, ldw, M, N, K, e, st);
         case 14: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16>(A, lda, W, ldw, M, N, K, e, st);   // with per-section cycle stamps
         case 40: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32>(A, lda, W, ldw, M, N, K, e, st);         // stamps on the shipped schedule
+        case 43: return launch<256, 256, 2, 4, 2, EpiResidual, 8 + 16 + 32>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);   // stamps, fp32 read-modify-write epilogue
+        case 44: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32>(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, (const float *)W, 1, 1.0f}, st);              // stamps, bias + GELU epilogue
         case 41: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32 + 256>(A, lda, W, ldw, M, N, K, e, st);   // ... epilogue without global stores
         case 42: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32 + 512>(A, lda, W, ldw, M, N, K, e, st);   // ... epilogue without the LDS round trip
         case 31: return launch<256, 256, 2, 4, 2, EpiResidual, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);   // fp32 read-modify-write epilogue (out must hold M x N floats; bias aliased, values irrelevant)

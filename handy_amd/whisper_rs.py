@@ -117,7 +117,7 @@ whisper_full_get_token_data whisper_full_get_token_data_from_state whisper_full_
 wmi_init_state_batch wmi_full_batch wmi_batch_n_utts wmi_batch_n_segments wmi_batch_segment_t0 wmi_batch_segment_t1
 wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks
 wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
-wmi_decode_logits_all wmi_debug_gemm wmi_debug_expand_blocks wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_version
+wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_version
 """.split()
 
 _lib = None
@@ -189,6 +189,7 @@ def load_library(path: Optional[str] = None):
     L.wmi_get_encoder_output.restype = ci; L.wmi_get_encoder_output.argtypes = [vp, fp]
     L.wmi_get_cross_kv.restype = ci; L.wmi_get_cross_kv.argtypes = [vp, ci, fp, fp]
     L.wmi_debug_gemm.restype = ci; L.wmi_debug_gemm.argtypes = [ci, ci, ci, fp, fp, fp]
+    L.wmi_debug_gemm_gelu.restype = ci; L.wmi_debug_gemm_gelu.argtypes = [ci, ci, ci, fp, fp, fp, vp]
     L.wmi_debug_expand_blocks.restype = ci; L.wmi_debug_expand_blocks.argtypes = [ci, vp, C.c_longlong, vp]
     L.wmi_set_profiling.argtypes = [vp, ci]
     L.wmi_set_pipeline_groups.argtypes = [vp, ci]

@@ -74,6 +74,7 @@ WHISPER_API int wmi_get_cross_kv(struct whisper_state *state, int layer, float *
 WHISPER_API int wmi_decode_logits_all(struct whisper_context *ctx, struct whisper_state *state, const whisper_token *tokens, int n_tokens, int n_past, float *logits_out);
 WHISPER_API int wmi_debug_gemm(int M, int N, int K, const float *A, const float *W, float *C);          /* C = f16(A) f16(W)^T on the device */
 
+WHISPER_API int wmi_debug_gemm_gelu(int M, int N, int K, const float *A, const float *W, const float *bias, unsigned short *out); /* f16 bits of gelu(f16(A) f16(W)^T + bias): the fc1 epilogue */
 /* The loader's device-side expansion of ggml block-quantised tensors (types 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0; 32 weights a
  * block) on host buffers: blocks -> out[n_blocks * 32] as fp16 bit patterns. */
 WHISPER_API int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_blocks, unsigned short *out);

@@ -32,6 +32,44 @@ def test_gemm_matches_numpy(wr, M, N, K):
     assert err <= 2e-3 * max(1.0, np.abs(ref).max()), err
 
 
+@pytest.mark.parametrize("M", [1024, 24576])
+def test_gelu_epilogue_over_every_f16_input(wr, M):
+    """The GELU fused into the fc1 GEMM (both tile paths: 64x64 for 1024 rows, 256x256 with the staged epilogue for 24576) on every finite fp16 value,
+    against ggml's definition -- the tanh form evaluated on the fp16 input and rounded to fp16 (the values of its lookup
+    table), 0 at and below -10, the input itself at and above 10. The kernel's exp and reciprocal are hardware
+    approximations: at most one fp16 ulp off (5e-7 absolute in the cancelling negative tail), on a small share of inputs."""
+    import ctypes as C
+    L = wr.load_library()
+    bits = np.arange(65536, dtype=np.uint16)
+    h = bits.view(np.float16)
+    vals = np.where(np.isfinite(h), h, np.float16(0)).astype(np.float32)
+    K = 64
+    A = np.zeros((M, K), np.float32)
+    n_per = 65536 // 1024
+    A[:1024, :n_per] = vals.reshape(1024, n_per)                           # value j of row i sits in column j
+    A[1024:] = A[:1024].repeat(1, axis=0)[np.arange(M - 1024) % 1024] if M > 1024 else 0
+    N = 256
+    W = np.zeros((N, K), np.float32); W[np.arange(K), np.arange(K)] = 1.0   # identity: out[:, :64] = A
+    out = np.empty((M, N), np.uint16)
+    assert L.wmi_debug_gemm_gelu(M, N, K, wr._fp(A), wr._fp(W), None, out.ctypes.data_as(C.c_void_p)) == 0
+    for r0 in range(0, M, 1024):
+        got = out[r0:r0 + 1024, :n_per].reshape(-1).view(np.float16).astype(np.float64)
+        x = vals.astype(np.float64)
+        ref = (0.5 * x * (1.0 + np.tanh(0.7978845608028654 * x * (1.0 + 0.044715 * x * x)))).astype(np.float16)
+        ref = np.where(x <= -10.0, np.float16(0), np.where(x >= 10.0, vals.astype(np.float16), ref))
+        gb = out[r0:r0 + 1024, :n_per].reshape(-1).astype(np.int32); rb = ref.view(np.uint16).astype(np.int32)
+        same_sign = (gb >> 15) == (rb >> 15)
+        ulp = np.where(same_sign, np.abs(gb - rb), (gb & 0x7fff) + (rb & 0x7fff))
+        # in the negative tail 1 + tanh cancels (in ggml's fp32 table as in the kernel's h - h/(exp(2u) + 1)): there the
+        # bound is absolute, 5e-7, a few ulps of fp16 subnormals
+        bad = (ulp > 1) & (np.abs(got - ref.astype(np.float64)) > 5e-7)
+        assert not bad.any(), (int(bad.sum()), vals[bad][:4], got[bad][:4], ref[bad][:4])
+        assert (ulp != 0).mean() <= 0.01, float((ulp != 0).mean())
+        big = np.abs(x) >= 10.0
+        assert np.array_equal(gb[big] & 0x7fff, rb[big] & 0x7fff)              # exact in the guarded ranges (up to the sign of zero)
+    assert not out[:, n_per:64].any() and not out[:, 64:].any()              # gelu(0) = 0 everywhere else
+
+
 @pytest.mark.parametrize("name", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0"])
 def test_block_expansion_is_bit_exact(wr, name):
     """The loader's device-side expansion of ggml block formats against the numpy expansion of the same bytes: identical
