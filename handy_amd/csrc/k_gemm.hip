@@ -95,13 +95,14 @@ struct EpiF32 {            // out[m][n] = acc + bias
 
 struct EpiResidual {       // x[m][n] += acc + bias   (fp32 residual stream, in place)
     static constexpr bool kWide = false;
+    static constexpr bool kReadsOutput = true;      // load() early, apply() later: the staged epilogue hides the read's latency
     float *x; long ldc; const float *bias;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
-        float *p = x + (long)m * ldc + n;
+    __device__ __forceinline__ f32x4 load(int m, int n) const { return *(const f32x4 *)(x + (long)m * ldc + n); }
+    __device__ __forceinline__ void apply(int m, int n, f32x4 a, f32x4 r) const {
         const f32x4 b = *(const f32x4 *)(bias + n);
-        const f32x4 r = *(const f32x4 *)p;
-        *(f32x4 *)p = r + (a + b);
+        *(f32x4 *)(x + (long)m * ldc + n) = r + (a + b);
     }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { apply(m, n, a, load(m, n)); }
 };
 
 struct EpiConv1 {          // rows have period P = 2T+2 per utterance; h1[m+1][n] = t < 2T ? gelu(acc+b) : 0
@@ -167,6 +168,32 @@ struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -
     }
 };
 
+// The V projection computed transposed, Vt = Wv xn^T: output row m = h*64 + e (a weight row), column n = b*T + t (an
+// activation row), so that the rows of a tile run along t -- the direction Vt[b][h][e][t] is contiguous in -- and go
+// through the wide staged epilogue like every other f16 output. (As columns of the fused QKV GEMM the V part leaves the
+// accumulators as 2-byte stores scattered over 64 rows of Vt: 45 000 cycles per tile against 9 000.)
+// T % 4 == 0: four consecutive columns never straddle two utterances.
+struct EpiVt {
+    static constexpr bool kWide = true;
+    f16 *Vt; const float *bias; int H, T, Tp, rows;
+    __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
+        const float b = bias[m];
+        return f16x4{(f16)(a[0] + b), (f16)(a[1] + b), (f16)(a[2] + b), (f16)(a[3] + b)};
+    }
+    __device__ __forceinline__ bool wide(int n) const { return true; }
+    __device__ __forceinline__ bool wide_block(int n0, int bn) const { return true; }
+    __device__ __forceinline__ void store4(int m, int n, f16x4 o) const {
+        if (n >= rows) return;
+        const int b = n / T, t = n - b * T;
+        *(f16x4 *)(Vt + (((long)b * H + (m >> 6)) * 64 + (m & 63)) * Tp + t) = o;
+    }
+    __device__ __forceinline__ void store8(int m, int n, f16x8 o) const {
+        store4(m, n, f16x4{o[0], o[1], o[2], o[3]});
+        store4(m, n + 4, f16x4{o[4], o[5], o[6], o[7]});
+    }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { store4(m, n, value(m, n, a)); }
+};
+
 struct EpiCrossKV {        // n = (layer*2 + kv)*d + h*64 + e ; out[slot(b)][layer][kv][h][t][64]
     static constexpr bool kWide = true;
     f16 *out; const float *bias; const int *slots; int d, H, T, Tp, n_layer;
@@ -213,6 +240,8 @@ struct EpiPartial {        // split-K partial sums: ws[split][m][n] = acc (no bi
 
 template <class Epi, class = void> struct is_splitk { static constexpr bool value = false; };
 template <class Epi> struct is_splitk<Epi, decltype((void)Epi::kSplitK)> { static constexpr bool value = Epi::kSplitK; };
+template <class Epi, class = void> struct reads_output { static constexpr bool value = false; };
+template <class Epi> struct reads_output<Epi, decltype((void)Epi::kReadsOutput)> { static constexpr bool value = Epi::kReadsOutput; };
 
 // ------------------------------------------------------------------------------------------ kernel
 // Workgroup id -> output tile. Physical ids p, p+8, ... share an XCD (one private L2 each): every XCD
@@ -318,11 +347,27 @@ __device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4
 // The same for epilogues that work on fp32 values (residual add, fp32 output, ...): the raw accumulators of one
 // 128-row half at a time (128 x 256 x 4 B = 128 KB) go through LDS and come back one whole row per wave
 // instruction, so the epilogue's loads and stores are 1 KB contiguous instead of 16 rows x 64 B.
+// An epilogue that adds to what the output already holds has its 16 rows per wave and half requested before the
+// accumulators go to LDS; the barriers here are the raw s_barrier after an LDS-only wait, so those requests stay in
+// flight across them (a __syncthreads() waits for every outstanding load).
 template <class Epi>
 __device__ __forceinline__ void write_tile_staged_f32(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, int wr, int wc, int wave, int lane, char *smem) {
     const int fr = lane & 15, fq = lane >> 4;
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
+    constexpr bool RMW = reads_output<Epi>::value;
+    f32x4 old[RMW ? 16 : 1];
+    auto request = [&](int hh) {
+        if constexpr (RMW) {
+#pragma unroll
+            for (int p = 0; p < 16; p++) {
+                const int m = m0 + hh * 128 + p * 8 + wave;
+                old[p] = f32x4{0, 0, 0, 0};
+                if (m < M) old[p] = epi.load(m, n0 + lane * 4);
+            }
+        }
+    };
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    request(0);
+    lds_barrier();                               // everybody's last fragment reads are done: the stage buffers are free
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
         if (wr == hh) {
@@ -334,14 +379,17 @@ __device__ __forceinline__ void write_tile_staged_f32(const Epi &epi, f32x4 (&ac
                     *(f32x4 *)(smem + row * 1024 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
                 }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int p = 0; p < 16; p++) {
             const int row = p * 8 + wave, m = m0 + hh * 128 + row;
             const f32x4 v = *(const f32x4 *)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
-            if (m < M) epi(m, n0 + lane * 4, v);
+            if (m < M) {
+                if constexpr (RMW) epi.apply(m, n0 + lane * 4, v, old[p]);
+                else epi(m, n0 + lane * 4, v);
+            }
         }
-        if (hh == 0) __syncthreads();
+        if (hh == 0) { request(1); lds_barrier(); }
     }
 }
 
@@ -502,7 +550,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
 }
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
-static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int splits = 1) {
+static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int splits = 1, int group_rows = 0) {
     if (M <= 0) return true;
     if (N % BN != 0 || K % BK != 0) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (tile %dx%d)\n", M, N, K, BM, BN); return false; }
     const int nblk = ((M + BM - 1) / BM) * (N / BN);
@@ -513,7 +561,7 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
         attr_set = true;
     }
     // rows per L2 group: a group of ~30-80 tiles per XCD measured best on the encoder shapes (6 rows x 5 columns, 5 x 15, 4 x 20)
-    const int nbn = N / BN, gm = g_tile_group_rows > 0 ? g_tile_group_rows : (nbn <= 8 ? 6 : (nbn <= 16 ? 5 : 4));
+    const int nbn = N / BN, gm = group_rows > 0 ? group_rows : g_tile_group_rows > 0 ? g_tile_group_rows : (nbn <= 8 ? 6 : (nbn <= 16 ? 5 : 4));
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, A, lda, W, ldw, M, N, K, gm, epi);
     return hipGetLastError() == hipSuccess;
 }
@@ -684,7 +732,14 @@ bool gemm_conv1(const f16 *melT, int n_mel, const f16 *W, int Kpad, int M, int d
 bool gemm_conv2(const f16 *h1, const f16 *W, int M, int d, float *x, const float *bias, const float *pe, int T, hipStream_t st) {
     return dispatch(h1, 2L * d, W, 3L * d, M, d, 3 * d, EpiConv2{x, d, bias, pe, T}, st);
 }
+// xn must be readable up to its row count rounded up to 256 (the engine's activation buffers are).
 bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *Kb, f16 *Vt, const float *bias, hipStream_t st) {
+    // Big batches: Q and K as one GEMM over the first 2d weight rows, V as its own transposed GEMM (see EpiVt) whose "rows"
+    // are the d weight rows and whose "columns" are the M activation rows. All tile rows of that GEMM form one L2 group.
+    const int Mp = (M + 255) / 256 * 256;
+    if (d % 256 == 0 && T % 4 == 0 && (long)(d / 256) * (Mp / 128) >= 192)
+        return dispatch(xn, d, W, d, M, 2 * d, d, EpiEncQKV{Q, Kb, Vt, bias, d, H, T, Tp}, st) &&
+               launch<256, 256, 2, 4, 2, EpiVt, kSpread | kFirstHalf>(W + (long)2 * d * d, d, xn, d, d, Mp, d, EpiVt{Vt, bias + 2 * d, H, T, Tp, M}, st, 1, d / 256);
     return dispatch(xn, d, W, d, M, 3 * d, d, EpiEncQKV{Q, Kb, Vt, bias, d, H, T, Tp}, st);
 }
 bool gemm_cross_kv(const f16 *enc, const f16 *W, int M, int d, int H, int T, int Tp, int n_layer, f16 *out, const float *bias, const int *slots, hipStream_t st) {
