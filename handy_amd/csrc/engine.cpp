@@ -302,7 +302,12 @@ bool Engine::encode_chunk(const std::vector<WinDesc> &wins, const std::vector<in
     for (int l = 0; l < Le_; l++) {
         const EncLayer &L = model->enc[l];
         PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(w.x.as<float>(), L.ln1_w, L.ln1_b, w.xn.as<f16>(), nullptr, M, d, nullptr, stream_));
-        PROF(WMI_K_ENC_GEMM, 2.0 * M * 3 * d * d, gemm_enc_qkv(w.xn.as<f16>(), L.wqkv, M, d, H_, T, Tp, w.q.as<f16>(), w.k.as<f16>(), w.vt.as<f16>(), L.bqkv, stream_));
+        if (gemm_enc_qkv_is_split(M, d, T)) {
+            PROF(WMI_K_ENC_GEMM, 2.0 * M * 2 * d * d, gemm_enc_qk(w.xn.as<f16>(), L.wqkv, M, d, H_, T, Tp, w.q.as<f16>(), w.k.as<f16>(), L.bqkv, stream_));
+            PROF(WMI_K_ENC_GEMM, 2.0 * M * d * d, gemm_enc_vt(w.xn.as<f16>(), L.wqkv, M, d, H_, T, Tp, w.vt.as<f16>(), L.bqkv, stream_));
+        } else {
+            PROF(WMI_K_ENC_GEMM, 2.0 * M * 3 * d * d, gemm_enc_qkv(w.xn.as<f16>(), L.wqkv, M, d, H_, T, Tp, w.q.as<f16>(), w.k.as<f16>(), w.vt.as<f16>(), L.bqkv, stream_));
+        }
         PROF(WMI_K_ENC_ATTN, 4.0 * E * (double)T * T * d, enc_attention(w.q.as<f16>(), w.k.as<f16>(), w.vt.as<f16>(), w.att.as<f16>(), E, H_, T, Tp, stream_));
         PROF(WMI_K_ENC_GEMM, 2.0 * M * d * d, gemm_residual(w.att.as<f16>(), d, L.wo, d, M, d, d, w.x.as<float>(), d, L.bo, stream_));
         PROF(WMI_K_ENC_OTHER, ln_bytes, layer_norm(w.x.as<float>(), L.ln2_w, L.ln2_b, w.xn.as<f16>(), nullptr, M, d, nullptr, stream_));

@@ -732,14 +732,22 @@ bool gemm_conv1(const f16 *melT, int n_mel, const f16 *W, int Kpad, int M, int d
 bool gemm_conv2(const f16 *h1, const f16 *W, int M, int d, float *x, const float *bias, const float *pe, int T, hipStream_t st) {
     return dispatch(h1, 2L * d, W, 3L * d, M, d, 3 * d, EpiConv2{x, d, bias, pe, T}, st);
 }
-// xn must be readable up to its row count rounded up to 256 (the engine's activation buffers are).
-bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *Kb, f16 *Vt, const float *bias, hipStream_t st) {
-    // Big batches: Q and K as one GEMM over the first 2d weight rows, V as its own transposed GEMM (see EpiVt) whose "rows"
-    // are the d weight rows and whose "columns" are the M activation rows. All tile rows of that GEMM form one L2 group.
+// Big batches: Q and K as one GEMM over the first 2d weight rows, V as its own transposed GEMM (see EpiVt) whose "rows"
+// are the d weight rows and whose "columns" are the M activation rows; all tile rows of that GEMM form one L2 group.
+// xn must then be readable up to its row count rounded up to 256 (the engine's activation buffers are).
+bool gemm_enc_qkv_is_split(int M, int d, int T) {
     const int Mp = (M + 255) / 256 * 256;
-    if (d % 256 == 0 && T % 4 == 0 && (long)(d / 256) * (Mp / 128) >= 192)
-        return dispatch(xn, d, W, d, M, 2 * d, d, EpiEncQKV{Q, Kb, Vt, bias, d, H, T, Tp}, st) &&
-               launch<256, 256, 2, 4, 2, EpiVt, kSpread | kFirstHalf>(W + (long)2 * d * d, d, xn, d, d, Mp, d, EpiVt{Vt, bias + 2 * d, H, T, Tp, M}, st, 1, d / 256);
+    return d % 256 == 0 && T % 4 == 0 && (long)(d / 256) * (Mp / 128) >= 192;
+}
+bool gemm_enc_qk(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *Kb, const float *bias, hipStream_t st) {
+    return dispatch(xn, d, W, d, M, 2 * d, d, EpiEncQKV{Q, Kb, nullptr, bias, d, H, T, Tp}, st);
+}
+bool gemm_enc_vt(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Vt, const float *bias, hipStream_t st) {
+    if (!gemm_enc_qkv_is_split(M, d, T)) return false;
+    const int Mp = (M + 255) / 256 * 256;
+    return launch<256, 256, 2, 4, 2, EpiVt, kSpread | kFirstHalf>(W + (long)2 * d * d, d, xn, d, d, Mp, d, EpiVt{Vt, bias + 2 * d, H, T, Tp, M}, st, 1, d / 256);
+}
+bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *Kb, f16 *Vt, const float *bias, hipStream_t st) {
     return dispatch(xn, d, W, d, M, 3 * d, d, EpiEncQKV{Q, Kb, Vt, bias, d, H, T, Tp}, st);
 }
 bool gemm_cross_kv(const f16 *enc, const f16 *W, int M, int d, int H, int T, int Tp, int n_layer, f16 *out, const float *bias, const int *slots, hipStream_t st) {

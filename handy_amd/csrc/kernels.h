@@ -11,6 +11,10 @@ bool gemm_residual(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
 bool gemm_conv1(const f16 *melT, int n_mel, const f16 *W, int Kpad, int M, int d, f16 *h1, const float *bias, int T2, hipStream_t st);
 bool gemm_conv2(const f16 *h1, const f16 *W, int M, int d, float *x, const float *bias, const float *pe, int T, hipStream_t st);
 bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *K, f16 *Vt, const float *bias, hipStream_t st);
+// the same projection as two launches (Q and K; V transposed) when gemm_enc_qkv_is_split says the batch is big enough
+bool gemm_enc_qkv_is_split(int M, int d, int T);
+bool gemm_enc_qk(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *K, const float *bias, hipStream_t st);
+bool gemm_enc_vt(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Vt, const float *bias, hipStream_t st);
 bool gemm_cross_kv(const f16 *enc, const f16 *W, int M, int d, int H, int T, int Tp, int n_layer, f16 *out, const float *bias, const int *slots, hipStream_t st);
 bool gemm_dec_qkv(const f16 *xn, const f16 *W, int M, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st);
 
