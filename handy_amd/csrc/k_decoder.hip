@@ -118,6 +118,9 @@ bool dec_self_attention(const f16 *q, const f16 *kc, const f16 *vc, const int *b
 }
 
 // Cross-attention: T (1500) keys per (row, head), 384 KB of K+V streamed per pair; 4 waves = 32 keys per pass.
+// The K and V loads carry the non-temporal hint: a decode step streams every utterance's cache once (31 GB at 1024
+// utterances) and nothing of it is read again before the next step, so keeping it out of the caches' retention is
+// worth 9 % of the kernel (6.1 -> 6.7 TB/s).
 // Rows that belong to one utterance (the beams of a beam search, the tokens of a prompt) read the same K and V:
 // a workgroup takes a group of up to NQ such rows (consecutive in the pass; the host passes {first row, count})
 // and applies every key it loads to all of them, so the cache is streamed once per group, not once per row.
@@ -144,19 +147,19 @@ __global__ __launch_bounds__(256) void dec_cross_attention_kernel(const f16 *__r
         for (; j + 96 < T; j += 128) {     // four independent key rows (8 x 16-byte loads per lane) in flight per iteration
             f16x8 k[4], v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { k[u] = *(const f16x8 *)(kp + (long)(j + 32 * u) * 64); v[u] = *(const f16x8 *)(vp + (long)(j + 32 * u) * 64); }
+            for (int u = 0; u < 4; u++) { k[u] = __builtin_nontemporal_load((const f16x8 *)(kp + (long)(j + 32 * u) * 64)); v[u] = __builtin_nontemporal_load((const f16x8 *)(vp + (long)(j + 32 * u) * 64)); }
 #pragma unroll
             for (int u = 0; u < 4; u++) attn_step(s[0], q[0], k[u], v[u]);
         }
     }
     for (; j + 32 < T; j += 64) {          // two independent key rows in flight per iteration
-        const f16x8 k0 = *(const f16x8 *)(kp + (long)j * 64), v0 = *(const f16x8 *)(vp + (long)j * 64);
-        const f16x8 k1 = *(const f16x8 *)(kp + (long)(j + 32) * 64), v1 = *(const f16x8 *)(vp + (long)(j + 32) * 64);
+        const f16x8 k0 = __builtin_nontemporal_load((const f16x8 *)(kp + (long)j * 64)), v0 = __builtin_nontemporal_load((const f16x8 *)(vp + (long)j * 64));
+        const f16x8 k1 = __builtin_nontemporal_load((const f16x8 *)(kp + (long)(j + 32) * 64)), v1 = __builtin_nontemporal_load((const f16x8 *)(vp + (long)(j + 32) * 64));
 #pragma unroll
         for (int c = 0; c < NQ; c++) { attn_step(s[c], q[c], k0, v0); attn_step(s[c], q[c], k1, v1); }
     }
     for (; j < T; j += 32) {
-        const f16x8 k0 = *(const f16x8 *)(kp + (long)j * 64), v0 = *(const f16x8 *)(vp + (long)j * 64);
+        const f16x8 k0 = __builtin_nontemporal_load((const f16x8 *)(kp + (long)j * 64)), v0 = __builtin_nontemporal_load((const f16x8 *)(vp + (long)j * 64));
 #pragma unroll
         for (int c = 0; c < NQ; c++) attn_step(s[c], q[c], k0, v0);
     }
@@ -205,7 +208,9 @@ bool cross_v_transpose(const f16 *ckv, const int *slots, int n_slots, f16 *vt, i
 //                            tile), because all of them feed one accumulator
 //   O^T[dim][row] += V^T P^T P^T goes from the score registers straight into the B operand; V^T comes from the transposed
 //                            copy in the key order that layout implies (two 8-byte loads per lane and 16 dims)
-// Every K and V byte of the head is read once per group; the four waves' partial results meet in LDS.
+// Every K and V byte of the head is read once per group; the four waves' partial results meet in LDS. (No non-temporal
+// hint on these loads, unlike the row-per-workgroup kernel: a 128-byte line here is consumed by several load
+// instructions and has to stay cached between them -- with the hint the kernel drops from 4.7 to 3.6 TB/s.)
 __global__ __launch_bounds__(256) void dec_cross_attention_mq_kernel(const f16 *__restrict__ qb, const f16 *__restrict__ ckv, const f16 *__restrict__ vt,
                                                                      const DecRow *__restrict__ rows, const int2 *__restrict__ groups, int d, int H, int T, int Tp,
                                                                      int n_layer, int layer, f16 *__restrict__ att) {
