@@ -103,12 +103,12 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const f16 *__re
     int j = wave * 8 + g;
     for (; j + 32 < n_kv; j += 64) {
         const long o0 = kv_off(j), o1 = kv_off(j + 32);
-        const f16x8 k0 = *(const f16x8 *)(kc + o0), v0 = *(const f16x8 *)(vc + o0);
-        const f16x8 k1 = *(const f16x8 *)(kc + o1), v1 = *(const f16x8 *)(vc + o1);
+        const f16x8 k0 = __builtin_nontemporal_load((const f16x8 *)(kc + o0)), v0 = __builtin_nontemporal_load((const f16x8 *)(vc + o0));
+        const f16x8 k1 = __builtin_nontemporal_load((const f16x8 *)(kc + o1)), v1 = __builtin_nontemporal_load((const f16x8 *)(vc + o1));
         attn_step(s, q, k0, v0);
         attn_step(s, q, k1, v1);
     }
-    for (; j < n_kv; j += 32) { const long o = kv_off(j); attn_step(s, q, *(const f16x8 *)(kc + o), *(const f16x8 *)(vc + o)); }
+    for (; j < n_kv; j += 32) { const long o = kv_off(j); attn_step(s, q, __builtin_nontemporal_load((const f16x8 *)(kc + o)), __builtin_nontemporal_load((const f16x8 *)(vc + o))); }
     attn_block_finish(s, red, tid, att + (long)m * d + head * 64);
 }
 bool dec_self_attention(const f16 *q, const f16 *kc, const f16 *vc, const int *block_table, const DecRow *rows, int M, int d, int H, f16 *att, hipStream_t st) {
