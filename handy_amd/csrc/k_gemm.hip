@@ -139,6 +139,8 @@ struct EpiConv2 {          // rows have period T+1; x[b*T+t][n] = gelu(acc+b) + 
 struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -> K[b][h][t][64]; [2d,3d): V -> Vt[b][h][64][Tp]
     static constexpr bool kWide = true;
     f16 *Q, *K, *Vt; const float *bias; int d, H, T, Tp;
+    int b0 = 0, base = 0;                   // begin_tile: utterance of the tile's first row, and that utterance's first row
+    __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = m0 / T; base = b0 * T; }
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
         if (n < d) a *= 0.125f;
@@ -146,8 +148,9 @@ struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -
     }
     __device__ __forceinline__ bool wide(int n) const { return n < 2 * d; }      // the V part is stored transposed, element by element
     __device__ __forceinline__ bool wide_block(int n0, int bn) const { return n0 + bn <= 2 * d; }
-    __device__ __forceinline__ void store8(int m, int n, f16x8 o) const {
-        const int b = m / T, t = m - b * T;
+    __device__ __forceinline__ void store8(int m, int n, f16x8 o) const {       // begin_tile has run
+        int b = b0, t = m - base;
+        if (T >= 256) { if (t >= T) { t -= T; b++; } } else { b = m / T; t = m - b * T; }
         const int part = n >= d, c = n - part * d, h = c >> 6, e = c & 63;
         *(f16x8 *)((part ? K : Q) + (((long)b * H + h) * Tp + t) * 64 + e) = o;
     }
@@ -176,6 +179,8 @@ struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -
 struct EpiVt {
     static constexpr bool kWide = true;
     f16 *Vt; const float *bias; int H, T, Tp, rows;
+    int b0 = 0, base = 0;                   // begin_tile: utterance of the tile's first column, and that utterance's first column
+    __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = n0 / T; base = b0 * T; }
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         const float b = bias[m];
         return f16x4{(f16)(a[0] + b), (f16)(a[1] + b), (f16)(a[2] + b), (f16)(a[3] + b)};
@@ -184,7 +189,8 @@ struct EpiVt {
     __device__ __forceinline__ bool wide_block(int n0, int bn) const { return true; }
     __device__ __forceinline__ void store4(int m, int n, f16x4 o) const {
         if (n >= rows) return;
-        const int b = n / T, t = n - b * T;
+        int b = b0, t = n - base;
+        if (T >= 256) { if (t >= T) { t -= T; b++; } } else { b = n / T; t = n - b * T; }
         *(f16x4 *)(Vt + (((long)b * H + (m >> 6)) * 64 + (m & 63)) * Tp + t) = o;
     }
     __device__ __forceinline__ void store8(int m, int n, f16x8 o) const {
@@ -197,9 +203,17 @@ struct EpiVt {
 struct EpiCrossKV {        // n = (layer*2 + kv)*d + h*64 + e ; out[slot(b)][layer][kv][h][t][64]
     static constexpr bool kWide = true;
     f16 *out; const float *bias; const int *slots; int d, H, T, Tp, n_layer;
+    int b0 = -1, base = 0, lk0 = 0, nbase = 0;      // begin_tile: utterance / (layer, k|v) of the tile's first row / column
+    __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = m0 / T; base = b0 * T; lk0 = n0 / d; nbase = lk0 * d; }
     __device__ __forceinline__ f16 *dest(int m, int n) const {
-        const int b = m / T, t = m - b * T;
-        const int lk = n / d, c = n - lk * d, h = c >> 6, e = c & 63;
+        int b, t, lk, c;
+        if (b0 >= 0 && T >= 256 && d >= 256) {
+            b = b0; t = m - base; if (t >= T) { t -= T; b++; }
+            lk = lk0; c = n - nbase; if (c >= d) { c -= d; lk++; }
+        } else {
+            b = m / T; t = m - b * T; lk = n / d; c = n - lk * d;
+        }
+        const int h = c >> 6, e = c & 63;
         const long slot = slots[b];
         return out + ((((slot * n_layer * 2 + lk) * H + h) * (long)Tp) + t) * 64 + e;
     }
@@ -240,6 +254,11 @@ struct EpiPartial {        // split-K partial sums: ws[split][m][n] = acc (no bi
 
 template <class Epi, class = void> struct is_splitk { static constexpr bool value = false; };
 template <class Epi> struct is_splitk<Epi, decltype((void)Epi::kSplitK)> { static constexpr bool value = Epi::kSplitK; };
+// Epilogues that map a row (or column) index to (utterance, frame) offer begin_tile(m0, n0): one integer division per
+// tile there instead of one per store (a 256-wide tile spans at most two utterances, so a compare finishes the job;
+// the compiler's division sequence is ~30 instructions, and the staged epilogue makes 16-32 stores per lane).
+template <class Epi, class = void> struct has_begin_tile { static constexpr bool value = false; };
+template <class Epi> struct has_begin_tile<Epi, decltype((void)&Epi::begin_tile)> { static constexpr bool value = true; };
 template <class Epi, class = void> struct reads_output { static constexpr bool value = false; };
 template <class Epi> struct reads_output<Epi, decltype((void)Epi::kReadsOutput)> { static constexpr bool value = Epi::kReadsOutput; };
 
@@ -530,6 +549,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
         if (ABL & 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); t_comp += t - t_prev; t_prev = t; }
     }
+    if constexpr (has_begin_tile<Epi>::value) epi.begin_tile(m0, n0);       // every tile shape is at most 256 x 256
     if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && Epi::kWide) {
         if (epi.wide_block(n0, BN)) write_tile_staged<Epi, (ABL >> 8) & 3>(epi, acc, M, m0, n0, wr, wc, wave, lane, smem);
         else write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
