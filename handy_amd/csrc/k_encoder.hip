@@ -346,14 +346,17 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
         for (int g = 0; g < 4; g++) {
             const f32x16 &o = blk ? o1 : o0;
             const f16x4 v4 = {(f16)(o[4 * g] * inv), (f16)(o[4 * g + 1] * inv), (f16)(o[4 * g + 2] * inv), (f16)(o[4 * g + 3] * inv)};
-            *(f16x4 *)(ob + (wave * 32 + r) * 128 + (blk * 32 + 8 * g + 4 * h) * 2) = v4;
+            // 16-byte chunk (4 blk + g) of row (wave * 32 + r) sits at chunk ^ (row & 7): the 32 lanes of a half-wave write one
+            // column of 32 different rows, which unswizzled is the same four banks 32 times over
+            const int orow = wave * 32 + r;
+            *(f16x4 *)(ob + orow * 128 + (((4 * blk + g) ^ (orow & 7)) << 4) + 8 * h) = v4;
         }
     __syncthreads();
     const int d = H * 64;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const int idx = p * 256 + tid, row = idx >> 3, ch = idx & 7, q = qblk * 128 + row;
-        if (q < T) *(f16x8 *)(att + ((long)b * T + q) * d + head * 64 + ch * 8) = *(const f16x8 *)(ob + row * 128 + ch * 16);
+        if (q < T) *(f16x8 *)(att + ((long)b * T + q) * d + head * 64 + ch * 8) = *(const f16x8 *)(ob + row * 128 + ((ch ^ (row & 7)) << 4));
     }
 }
 
