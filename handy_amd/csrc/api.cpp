@@ -482,6 +482,13 @@ int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {
     WMI_CATCH(-1)
 }
 
+int wmi_bench_lds_pattern(int pattern, int do_read, int iters, float *ms_out) {
+    WMI_TRY
+    if (pattern < 0 || pattern > 6 || iters <= 0 || !ms_out) return -1;
+    return wmi::lds_pattern_bench(pattern, do_read, iters, ms_out) ? 0 : -1;
+    WMI_CATCH(-1)
+}
+
 // LayerNorm harness: `iters` launches of one variant over M rows of width d (fp32 in, fp16 out), average ms by HIP events.
 int wmi_bench_layer_norm(int M, int d, int variant, int iters, float *ms_out) {
     WMI_TRY

@@ -360,6 +360,52 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     }
 }
 
+// Micro-benchmark (harness only): time of 16-byte LDS writes / reads (four per iteration, 8 workgroups per CU) under a lane ->
+// (row, slot) pattern; rows are 128 bytes.
+//   0 linear (lane l -> byte 16 l)            1 one column: row l, slot 0
+//   2 four lanes per row, slots 0,2,4,6, swizzle (row >> 1) & 7 (the attention kernel's tile writes)
+//   3 as 2 with swizzle row & 7               4 32 rows per half-wave, slot = lane >> 5, swizzle (row >> 1) & 7 (its fragment reads)
+//   5 as 4 with swizzle row & 7               6 16 rows per quarter-wave, slot = lane >> 4, swizzle row & 7 (the GEMM's fragment reads)
+__global__ __launch_bounds__(256) void lds_pattern_kernel(int pattern, int do_read, int iters, float *sink) {
+    __shared__ __attribute__((aligned(16))) char buf[16384];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int row = 0, slot = 0;
+    switch (pattern) {
+        case 0: row = lane >> 3; slot = lane & 7; break;
+        case 1: row = lane; slot = 0; break;
+        case 2: row = lane >> 2; slot = ((lane & 3) * 2) ^ ((row >> 1) & 7); break;
+        case 3: row = lane >> 2; slot = ((lane & 3) * 2) ^ (row & 7); break;
+        case 4: row = lane & 31; slot = (lane >> 5) ^ ((row >> 1) & 7); break;
+        case 5: row = lane & 31; slot = (lane >> 5) ^ (row & 7); break;
+        default: row = lane & 15; slot = (lane >> 4) ^ (row & 7); break;
+    }
+    char *p = buf + ((wave * 16 + row) & 127) * 128 + slot * 16;
+    f32x4 v = {(float)lane, 1.0f, 2.0f, 3.0f}, acc = {0, 0, 0, 0};
+    for (int i = 0; i < iters; i++) {
+        if (do_read) {
+            f32x4 t0, t1, t2, t3;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4\n\tds_read_b128 %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"((unsigned)(size_t)p) : "memory");
+            acc += t0 + t1 + t2 + t3;
+        } else {
+            asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %1\n\tds_write_b128 %0, %1\n\tds_write_b128 %0, %1" ::"v"((unsigned)(size_t)p), "v"(v) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (sink && acc[0] == 12345.678f) sink[threadIdx.x] = acc[0] + *(float *)p;
+}
+bool lds_pattern_bench(int pattern, int do_read, int iters, float *ms_out) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return false;
+    hipLaunchKernelGGL(lds_pattern_kernel, dim3(2048), dim3(256), 0, nullptr, pattern, do_read, 16, (float *)nullptr);
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(lds_pattern_kernel, dim3(2048), dim3(256), 0, nullptr, pattern, do_read, iters, (float *)nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms_out, e0, e1) == hipSuccess;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ok && hipGetLastError() == hipSuccess;
+}
+
 bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st) {
     if (B <= 0) return true;
     if (Tp % 128 != 0 || T > Tp) { log_msg(2, "enc_attention: bad padding T=%d Tp=%d\n", T, Tp); return false; }

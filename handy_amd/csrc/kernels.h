@@ -63,6 +63,7 @@ bool mel_window_normalized(const float *mel, const WinDesc *wins, int n_win, int
 
 // ---- k_encoder.hip --------------------------------------------------------------------------
 // y = LayerNorm(x) * w + b (eps 1e-5); writes fp16 (out16) and/or fp32 (out32); rows gathered through `gather` if given
+bool lds_pattern_bench(int pattern, int do_read, int iters, float *ms_out);   // LDS access-pattern micro-benchmark (harness)
 bool layer_norm_variant(int variant, const float *x, const float *w, const float *b, f16 *out16, int M, int d, hipStream_t st);   // benchmark harness
 bool layer_norm(const float *x, const float *w, const float *b, f16 *out16, float *out32, int M, int d, const int *gather, hipStream_t st);
 // non-causal attention over T keys (padded to Tp), heads of 64: Q,K [B][H][Tp][64], Vt [B][H][64][Tp] -> att [B*T][H*64]

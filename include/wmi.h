@@ -82,6 +82,7 @@ WHISPER_API int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long 
 WHISPER_API int wmi_debug_read_gemm_stamps(unsigned long long *out, int n);                             /* harness: per-section cycle sums of variant 14 */
 WHISPER_API void wmi_debug_set_tile_group(int rows);                                                    /* harness knob: tile rows per L2 group */
 WHISPER_API int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_variant, float *max_abs_diff); /* harness */
+WHISPER_API int wmi_bench_lds_pattern(int pattern, int do_read, int iters, float *ms_out);                /* 16-byte LDS access patterns, one workgroup per CU (harness) */
 WHISPER_API int wmi_bench_layer_norm(int M, int d, int variant, int iters, float *ms_out);            /* LayerNorm A/B harness (variant 100 = the shipped kernel) */
 WHISPER_API int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out);            /* tile-shape A/B harness, random fp16 operands */
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) > 100
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
-    assert sorted(set(declared)) == sorted(set(wr.DECLARED_SYMBOLS) | {"wmi_bench_gemm", "wmi_bench_layer_norm", "wmi_debug_set_tile_group", "wmi_debug_read_gemm_stamps", "wmi_debug_gemm_variant_diff"})
+    assert sorted(set(declared)) == sorted(set(wr.DECLARED_SYMBOLS) | {"wmi_bench_gemm", "wmi_bench_layer_norm", "wmi_bench_lds_pattern", "wmi_debug_set_tile_group", "wmi_debug_read_gemm_stamps", "wmi_debug_gemm_variant_diff"})
     out = subprocess.run(["nm", "-D", "--defined-only", wr.LIB_PATH], capture_output=True, text=True).stdout
     assert "ggml_" not in out          # Handy isolates llama.cpp in a sidecar because of ggml symbol clashes (local_llm.rs:1-4)
 
