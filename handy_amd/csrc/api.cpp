@@ -287,7 +287,8 @@ int whisper_full_with_state(struct whisper_context *ctx, struct whisper_state *s
     const int ns[1] = {n_samples};
     static const float zero = 0.0f;
     if (n_samples == 0) ptrs[0] = &zero;
-    return wmi_full_batch(ctx, s, params, ptrs, ns, 1, 0);
+    const int rc = wmi_full_batch(ctx, s, params, ptrs, ns, 1, 0);
+    return rc != 0 ? rc : wmi_batch_rc(s, 0);          // one utterance: its own failure is the call's failure
 }
 int whisper_full(struct whisper_context *ctx, struct whisper_full_params params, const float *samples, int n_samples) {
     return ctx ? whisper_full_with_state(ctx, ctx->default_state, params, samples, n_samples) : -1;
@@ -314,6 +315,7 @@ whisper_token_data wmi_batch_token_data(struct whisper_state *s, int utt, int i,
     if (!g || j < 0 || j >= (int)g->tokens.size()) { whisper_token_data z{}; return z; }
     return g->tokens[j];
 }
+int wmi_batch_rc(struct whisper_state *s, int utt) { Engine *e = ENG(s); return e && utt >= 0 && utt < (int)e->results.size() ? e->results[utt].rc : -1; }
 int wmi_batch_lang_id(struct whisper_state *s, int utt) { Engine *e = ENG(s); return e && utt >= 0 && utt < (int)e->results.size() ? e->results[utt].lang_id : -1; }
 int wmi_batch_n_fallbacks(struct whisper_state *s, int utt) { Engine *e = ENG(s); return e && utt >= 0 && utt < (int)e->results.size() ? e->results[utt].n_fallbacks : 0; }
 
@@ -464,7 +466,7 @@ int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = -1;
     if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess &&
-        hipMalloc(&dc, std::max(Mp * N * 4 + 4096, wmi::gemm_splitk_workspace_bytes((int)Mp, N))) == hipSuccess &&      // variant 30 writes split-K partials here, 31 fp32 rows
+        hipMalloc(&dc, std::max(Mp * N * 4 + 4096, wmi::gemm_splitk_workspace_bytes((int)Mp, N, K) + 4096)) == hipSuccess &&      // variant 30 writes split-K partials here, 31 fp32 rows
         hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
         hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         bool ok = true;

@@ -146,7 +146,13 @@ bool Engine::ensure_rows(int rows) {
               datt_.ensure(R * d_ * sizeof(f16)) && dhid_.ensure(R * 4 * d_ * sizeof(f16));
     const size_t meta = R * sizeof(DecRow) + (size_t)lrows_cap_ * (sizeof(SampleRow) + sizeof(int) * (kMaxPagesPerSeq + 1)) + 2 * R * sizeof(int2) + 4096;
     ok = ok && meta_dev_.ensure(meta) && meta_host_.ensure(meta);
-    ok = ok && splitk_ws_.ensure(gemm_splitk_workspace_bytes((int)std::min<size_t>(R, kSplitMaxRows), d_), false);
+    // split-K partial sums: the largest ws[splits][rows][N] over the four weight shapes of a decoder layer (at d < 853 the
+    // QKV and at d < 640 the fc1 projection split too, and their N is 3d and 4d)
+    const int ws_rows = (int)std::min<size_t>(R, kSplitMaxRows);
+    size_t ws_bytes = 4096;
+    for (const auto &nk : {std::pair<int, int>{3 * d_, d_}, {d_, d_}, {4 * d_, d_}, {d_, 4 * d_}})
+        ws_bytes = std::max(ws_bytes, gemm_splitk_workspace_bytes(ws_rows, nk.first, nk.second));
+    ok = ok && splitk_ws_.ensure(ws_bytes, false);
     if (ok) rows_cap_ = (int)R;
     return ok;
 }
@@ -442,7 +448,7 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     prof_stream_ = stream_;
     const bool fused_ln = s_dd > 1 && s_fc2 > 1;      // x += ... and the next LayerNorm in one kernel
     auto residual_ln = [&](const f16 *a, int K, const f16 *Wt, const float *bias, int splits, const float *lw, const float *lb, f16 *out, const int *gather, int n_out) -> bool {
-        PROF(WMI_K_DEC_GEMM, 2.0 * d * K, gemm_splitk(a, K, Wt, K, R, d, K, splits, ws, stream_));
+        PROF(WMI_K_DEC_GEMM, 2.0 * d * K, gemm_splitk(a, K, Wt, K, R, d, K, splits, ws, splitk_ws_.cap, stream_));
         PROF(WMI_K_DEC_OTHER, ln_bytes, splitk_residual_ln(dx_.as<float>(), ws, splits, bias, lw, lb, out, R, d, gather, n_out, stream_));
         return true;
     };
@@ -452,7 +458,7 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         f16 *kl = kp + l * layer_stride_, *vl = vp + l * layer_stride_;
         if (!fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln1_w, D.ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
         if (s_qkv > 1) {
-            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_splitk(dxn_.as<f16>(), d, D.wqkv, d, R, 3 * d, d, s_qkv, ws, stream_));
+            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_splitk(dxn_.as<f16>(), d, D.wqkv, d, R, 3 * d, d, s_qkv, ws, splitk_ws_.cap, stream_));
             PROF(WMI_K_DEC_OTHER, (double)R * 3 * d * 2, splitk_dec_qkv(ws, s_qkv, D.bqkv, d_rows, R, d, H_, dq_.as<f16>(), kl, vl, stream_));
         } else {
             PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_dec_qkv(dxn_.as<f16>(), D.wqkv, R, d, H_, dq_.as<f16>(), kl, vl, D.bqkv, d_rows, stream_));
@@ -464,7 +470,7 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
             PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.lnx_w, D.lnx_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
         }
         if (s_dd > 1) {
-            PROF(WMI_K_DEC_GEMM, w1, gemm_splitk(dxn_.as<f16>(), d, D.xq, d, R, d, d, s_dd, ws, stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_splitk(dxn_.as<f16>(), d, D.xq, d, R, d, d, s_dd, ws, splitk_ws_.cap, stream_));
             PROF(WMI_K_DEC_OTHER, (double)R * d * 2, splitk_f16(ws, s_dd, D.bxq, 0, 0.125f, dq_.as<f16>(), R, d, stream_));
         } else {
             PROF(WMI_K_DEC_GEMM, w1, gemm_f16(dxn_.as<f16>(), d, D.xq, d, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_));
@@ -479,7 +485,7 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
             PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
         }
         if (s_fc1 > 1) {
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_splitk(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, s_fc1, ws, stream_));
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_splitk(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, s_fc1, ws, splitk_ws_.cap, stream_));
             PROF(WMI_K_DEC_OTHER, (double)R * 4 * d * 2, splitk_f16(ws, s_fc1, D.b1, 1, 1.0f, dhid_.as<f16>(), R, 4 * d, stream_));
         } else {
             PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_));
@@ -699,15 +705,16 @@ struct Engine::Run {
     void init_utt(Utt &u) {
         const Model &M = *E.model;
         u.dec.resize(n_decoders);
-        for (Decoder &d : u.dec) d.rng = std::mt19937(0);
+        // decoder j draws from its own generator (seed j): the best_of decoders start from the same prompt logits and
+        // cache, so one shared seed would make every one of them draw the same tokens
+        for (int j = 0; j < n_decoders; j++) u.dec[j].rng = std::mt19937((uint32_t)j);
         u.n_len = E.utt_n_len_[u.mel_idx]; u.n_len_org = E.utt_n_len_org_[u.mel_idx];
         u.seek_start = P.offset_ms / 10;
         u.seek_end = P.duration_ms == 0 ? u.n_len_org : u.seek_start + P.duration_ms / 10;
         u.temps.clear();
         if (P.temperature_inc > 0.0f) { for (float t = P.temperature; t < 1.0f + 1e-6f && u.temps.size() < 16; t += P.temperature_inc) u.temps.push_back(t); }
         else u.temps.push_back(P.temperature);
-        if (!P.no_context) { /* text context would carry over between calls of one state; a batch run starts clean */ }
-        u.prompt_past = initial_prompt_tokens;
+        u.prompt_past = initial_prompt_tokens;         // caller's prompt tokens, then (one-utterance calls) the previous call's text context
         u.no_timestamps = P.no_timestamps;
         const bool detect = P.language == nullptr || P.language[0] == 0 || !strcmp(P.language, "auto") || P.detect_language;
         u.lang_id = 0;
@@ -963,12 +970,20 @@ int Engine::Run::run(const float *const *pcm, const int *n, int B, bool on_devic
     initial_prompt_tokens.clear();
     if (P.prompt_tokens && P.prompt_n_tokens > 0) initial_prompt_tokens.assign(P.prompt_tokens, P.prompt_tokens + P.prompt_n_tokens);
     else if (P.initial_prompt && P.initial_prompt[0]) initial_prompt_tokens = tokenize(V, P.initial_prompt);
+    // the ids index the token embedding on the device: reject what is not a token of this model
+    for (int t : initial_prompt_tokens)
+        if (t < 0 || t >= M.hp.n_vocab) { log_msg(2, "whisper_full: prompt token %d is outside the vocabulary (%d tokens)\n", t, M.hp.n_vocab); return -2; }
+    // text context kept from the previous call of this state (whisper_full with no_context = false): the caller's prompt
+    // tokens go in front of it. Only the one-utterance call has a "previous call" in this sense.
+    if (P.no_context || !single) E.carry_prompt_past.clear();
+    if (single && !E.carry_prompt_past.empty()) initial_prompt_tokens.insert(initial_prompt_tokens.end(), E.carry_prompt_past.begin(), E.carry_prompt_past.end());
     E.results.assign(B, UttResult{});
     int rc = 0;
     for (int g0 = 0; g0 < B; g0 += E.max_utts_) {
         const int r = run_group(pcm, n, g0, std::min(E.max_utts_, B - g0), on_device);
         if (r != 0 && rc == 0) rc = r;
     }
+    if (single && rc == 0 && !P.no_context && !utts.empty()) E.carry_prompt_past = utts[0].prompt_past;
     return rc;
 }
 
@@ -1091,18 +1106,22 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
         // ---- one decoder pass over every ready sequence that wants logits
         rows.clear(); srows.clear(); seqs.clear(); copies.clear(); lref.clear();
         in_pass.assign(G, 0);
-        bool fail = false;
-        for (int i = 0; i < G && !fail; i++) {
+        for (int i = 0; i < G; i++) {
             Utt &u = utts[i];
             if (u.enc_ev || gated[i]) continue;
+            // an utterance whose sequences find no room in the K/V page pool fails alone: its rows leave the pass again
+            const size_t r0 = rows.size(), s0 = srows.size(), q0 = seqs.size(), c0 = copies.size(), l0 = lref.size();
+            bool fail = false;
             if (u.phase == Phase::LangDecode) {
                 Decoder &d = u.dec[0];
                 E.page_release(d.pages); d.n_kv = 0;
                 DecRow r{V.sot, 0, (int)seqs.size(), u.slot, 0, (int)srows.size()};
-                if (!E.append_kv_slot(d, 0, copies, r.kv_index)) { fail = true; break; }
-                SampleRow s{}; s.flags = 256; s.max_initial = -1; s.topk = 0;
-                rows.push_back(r); srows.push_back(s); seqs.push_back(&d); lref.push_back({i, -1});
-                in_pass[i] = 1;
+                if (!E.append_kv_slot(d, 0, copies, r.kv_index)) fail = true;
+                else {
+                    SampleRow s{}; s.flags = 256; s.max_initial = -1; s.topk = 0;
+                    rows.push_back(r); srows.push_back(s); seqs.push_back(&d); lref.push_back({i, -1});
+                    in_pass[i] = 1;
+                }
             } else if (u.phase == Phase::Prompt) {
                 Decoder &d = u.dec[0];
                 const int sidx = (int)seqs.size();
@@ -1113,7 +1132,7 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
                     if (t == u.n_prompt - 1) { r.logit_row = (int)srows.size(); srows.push_back(sample_state(u, d)); lref.push_back({i, 0}); }
                     rows.push_back(r);
                 }
-                in_pass[i] = 1;
+                if (!fail) in_pass[i] = 1;
             } else if (u.phase == Phase::Step) {
                 for (int j = 0; j < u.n_cur; j++) {
                     Decoder &d = u.dec[j];
@@ -1124,12 +1143,21 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
                     srows.push_back(sample_state(u, d));
                     rows.push_back(r); seqs.push_back(&d); lref.push_back({i, j});
                 }
-                u.i++;
-                in_pass[i] = 1;
+                if (!fail) { u.i++; in_pass[i] = 1; }
+            }
+            if (fail) {
+                rows.resize(r0); srows.resize(s0); seqs.resize(q0); copies.resize(c0); lref.resize(l0);
+                release_decoders(u);
+                in_pass[i] = 0;
+                u.rc = -8; u.phase = Phase::Done;
             }
         }
-        if (fail) { rc = -8; break; }
-        if (rows.empty()) break;           // every utterance is Done
+        if (rows.empty()) {
+            bool all_done = true;
+            for (int i = 0; i < G; i++) all_done &= utts[i].phase == Phase::Done;
+            if (all_done) break;
+            continue;                      // the only candidates of this round failed; others still wait for their encoder chunk
+        }
         t0 = now_ms();
         const int T = E.enc_T_;
         if (!E.decoder_pass(rows, srows, seqs, copies, T, false, nullptr)) { rc = -7; break; }
@@ -1175,7 +1203,9 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
         }
     }
     if (rc) for (int l = 0; l < kEncLanes; l++) (void)hipStreamSynchronize(E.enc_streams_[l]);        // an early exit must not leave encoder work behind the caller's back
-    for (Utt &u : utts) { release_decoders(u); if (u.rc != 0) { E.results[u.index].rc = u.rc; if (!rc) rc = u.rc; } }
+    // rc is the failure of the batch as a whole (a HIP error, an abort); an utterance that failed on its own (no language
+    // found, no room in the K/V pool) carries its code in its result and does not fail the others
+    for (Utt &u : utts) { release_decoders(u); if (u.rc != 0) E.results[u.index].rc = u.rc; else if (rc != 0) E.results[u.index].rc = rc; }
     return rc;
 }
 

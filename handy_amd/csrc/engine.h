@@ -119,6 +119,7 @@ public:
     Model *model;
     std::vector<UttResult> results;
     int force_tokens = 0;
+    std::vector<int> carry_prompt_past;  // text context of the last one-utterance call (used when the next one sets no_context = false)
     int window_cache_cap = 0;            // windows remembered between calls (0 = off)
     std::deque<WindowMemo> window_memos;
     long window_cache_hits = 0, window_cache_stores = 0;

@@ -17,6 +17,8 @@
 // Bound: MFMA (dense fp16 peak ~2.5 PFLOP/s). Algorithmic work: 2*M*N*K flop per launch.
 #include "kernels.h"
 
+#include <atomic>
+
 namespace wmi {
 
 constexpr int BK = 64;             // halfs per K-step (128 B rows in LDS)
@@ -575,10 +577,13 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
     if (N % BN != 0 || K % BK != 0) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (tile %dx%d)\n", M, N, K, BM, BN); return false; }
     const int nblk = ((M + BM - 1) / BM) * (N / BN);
     constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the opt-in to more than 64 KB of dynamic LDS is per device (and per kernel instantiation): one bit per device id
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
         if (hipFuncSetAttribute((const void *)gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        attr_set = true;
+        attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
     // rows per L2 group: a group of ~30-80 tiles per XCD measured best on the encoder shapes (6 rows x 5 columns, 5 x 15, 4 x 20)
     const int nbn = N / BN, gm = group_rows > 0 ? group_rows : g_tile_group_rows > 0 ? g_tile_group_rows : (nbn <= 8 ? 6 : (nbn <= 16 ? 5 : 4));
@@ -621,7 +626,7 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 41: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32 + 256>(A, lda, W, ldw, M, N, K, e, st);   // ... epilogue without global stores
         case 42: return launch<256, 256, 2, 4, 2, EpiF16, 8 + 16 + 32 + 512>(A, lda, W, ldw, M, N, K, e, st);   // ... epilogue without the LDS round trip
         case 31: return launch<256, 256, 2, 4, 2, EpiResidual, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);   // fp32 read-modify-write epilogue (out must hold M x N floats; bias aliased, values irrelevant)
-        case 30: return gemm_splitk(A, lda, W, ldw, M, N, K, gemm_pick_splits(N, K), (float *)out, st);   // the decoder's skinny path (out must hold the partials)
+        case 30: return gemm_splitk(A, lda, W, ldw, M, N, K, gemm_pick_splits(N, K), (float *)out, gemm_splitk_workspace_bytes(M, N, K), st);   // the decoder's skinny path (out must hold the partials)
         case 22: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, e, st);   // loads + MFMA, fragments read once
         case 23: return launch<256, 256, 2, 4, 2, EpiF16, kNoLoads | kNoMfma>(A, lda, W, ldw, M, N, K, e, st);                   // LDS fragment reads only
         case 24: return launch<256, 256, 2, 4, 2, EpiF16, kNoLdsReads | kNoMfma | kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, e, st);   // loads only
@@ -722,10 +727,15 @@ static int skinny_steps(int N, int K) {
     return pick && (nk / pick) > 1 ? pick : 0;
 }
 int gemm_pick_splits(int N, int K) { const int ns = skinny_steps(N, K); return ns ? K / BK / ns : 1; }
-size_t gemm_splitk_workspace_bytes(int rows, int n) { return (size_t)16 * rows * n * sizeof(float); }     // splits <= 16 by construction (K <= 6144)
-bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, int splits, float *ws, hipStream_t st) {
+// Bytes of partial sums one split GEMM of `rows` rows writes: ws[splits][rows][N]. 0 when (N, K) does not split.
+size_t gemm_splitk_workspace_bytes(int rows, int N, int K) {
+    const int splits = gemm_pick_splits(N, K);
+    return splits > 1 ? (size_t)splits * rows * N * sizeof(float) : 0;
+}
+bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, int splits, float *ws, size_t ws_bytes, hipStream_t st) {
     const int ns = splits > 0 && K % (splits * BK) == 0 ? K / BK / splits : 0;
     if (ns < 1 || ns > 6 || N % 64 != 0 || splits > 16) { log_msg(2, "gemm_splitk: bad split %d for M=%d N=%d K=%d\n", splits, M, N, K); return false; }
+    if ((size_t)splits * M * N * sizeof(float) > ws_bytes) { log_msg(2, "gemm_splitk: %d x %d x %d partial sums exceed the %zu-byte workspace\n", splits, M, N, ws_bytes); return false; }
     const dim3 grid(N / 64, splits, (M + 127) / 128);
 #define WMI_SKINNY(NS_) case NS_: hipLaunchKernelGGL((gemm_skinny_kernel<NS_>), grid, dim3(256), NS_ * 8192, st, A, lda, W, ldw, M, N, ws); break;
     switch (ns) { WMI_SKINNY(1) WMI_SKINNY(2) WMI_SKINNY(3) WMI_SKINNY(4) WMI_SKINNY(5) WMI_SKINNY(6) }

@@ -20,8 +20,8 @@ bool gemm_dec_qkv(const f16 *xn, const f16 *W, int M, int d, int H, f16 *q, f16 
 
 // split-K path of the decoder (partials in ws, added up by the splitk_* consumers of k_decoder.hip)
 int gemm_pick_splits(int N, int K);                       // 1 = use the fused-epilogue kernels
-size_t gemm_splitk_workspace_bytes(int rows, int n);
-bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, int splits, float *ws, hipStream_t st);
+size_t gemm_splitk_workspace_bytes(int rows, int N, int K);   // bytes of ws[splits][rows][N] for this weight shape (0: it does not split)
+bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, int splits, float *ws, size_t ws_bytes, hipStream_t st);
 
 extern int g_tile_group_rows;
 bool gemm_read_stamps(unsigned long long *out, int n);

@@ -51,6 +51,10 @@ ARCHS = {
     "micro-v3": (51866, 128, 2, 2, 3, 128),
     # tiny's width with two layers each: wide enough for the decoder's split-K GEMM path (K = 384 = 6 K-steps)
     "mini": (51865, 384, 6, 2, 2, 80),
+    # base's and small's widths with few layers: the widths at which the decoder's QKV (d < 853) and fc1 (d < 640) projections
+    # take the split-K path as well
+    "mini512": (51865, 512, 8, 2, 3, 80),
+    "mini768": (51865, 768, 12, 2, 3, 80),
 }
 
 

@@ -60,8 +60,8 @@ class TranscriptionManager:
         # 30 s windows remembered between calls: live coaching transcribes the whole growing recording every 3 s
         # (reference: src-tauri/src/live_coaching.rs:84-97); 0 turns the memo off
         self.window_cache = window_cache
-        # engine_factory(path, gpu_device, max_batch) -> object with transcribe_batch(list of arrays, WhisperInferenceParams) -> list of str
-        # and close(); the default drives libwhisper_mi355.so, tests inject a stand-in to exercise the queueing on a CPU
+        # engine_factory(path, gpu_device, max_batch) -> object with transcribe_batch(list of arrays, WhisperInferenceParams) -> list with a
+        # str (or, for an utterance that failed on its own, an exception) per array, and close(); the default drives libwhisper_mi355.so, tests inject a stand-in to exercise the queueing on a CPU
         self._engine_factory = engine_factory or _HipBatchEngine
         self._engine = None
         self._lock = threading.Lock()
@@ -143,8 +143,11 @@ class TranscriptionManager:
             try:
                 texts = eng.transcribe_batch([r.audio for r in batch], params)
                 for r, t in zip(batch, texts):
-                    r.text = t
-            except BaseException as e:         # every caller of the failed batch sees the failure
+                    if isinstance(t, BaseException):   # this utterance failed on its own; the other callers keep their text
+                        r.error = t
+                    else:
+                        r.text = t
+            except BaseException as e:         # the batch as a whole failed: every caller of it sees the failure
                 for r in batch:
                     r.error = e
             with self._lock:
@@ -165,7 +168,11 @@ class _HipBatchEngine:
     def transcribe_batch(self, audios, params) -> List[str]:
         fp = self._proto._full_params(params)
         self.state.full_batch(fp, audios)
-        return ["".join(s.text for s in self.state.batch_segments(u)) for u in range(len(audios))]
+        out = []
+        for u in range(len(audios)):
+            rc = self.state.batch_rc(u)
+            out.append(wr.WhisperError("GenericError", rc) if rc != 0 else "".join(s.text for s in self.state.batch_segments(u)))
+        return out
 
     def set_window_cache(self, n: int):
         self.state.set_window_cache(n)

@@ -115,7 +115,7 @@ whisper_full_get_segment_text whisper_full_get_segment_text_from_state whisper_f
 whisper_full_get_token_text whisper_full_get_token_text_from_state whisper_full_get_token_id whisper_full_get_token_id_from_state
 whisper_full_get_token_data whisper_full_get_token_data_from_state whisper_full_get_token_p whisper_full_get_token_p_from_state
 wmi_init_state_batch wmi_full_batch wmi_batch_n_utts wmi_batch_n_segments wmi_batch_segment_t0 wmi_batch_segment_t1
-wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks
+wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks wmi_batch_rc
 wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
 wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_version
 """.split()
@@ -183,6 +183,7 @@ def load_library(path: Optional[str] = None):
     L.wmi_batch_token_data.restype = whisper_token_data; L.wmi_batch_token_data.argtypes = [vp, ci, ci, ci]
     L.wmi_batch_lang_id.restype = ci; L.wmi_batch_lang_id.argtypes = [vp, ci]
     L.wmi_batch_n_fallbacks.restype = ci; L.wmi_batch_n_fallbacks.argtypes = [vp, ci]
+    L.wmi_batch_rc.restype = ci; L.wmi_batch_rc.argtypes = [vp, ci]
     L.wmi_set_force_tokens.argtypes = [vp, ci]; L.wmi_set_beam_candidates_sampled.argtypes = [vp, ci]
     L.wmi_mel_batch_device.restype = ci; L.wmi_mel_batch_device.argtypes = [vp, vp, vp, C.POINTER(C.c_longlong), C.POINTER(ci), ci]
     L.wmi_get_mel.restype = ci; L.wmi_get_mel.argtypes = [vp, ci, fp, ci]
@@ -425,6 +426,7 @@ class WhisperState:
         return [t for s in self.batch_segments(utt) for t in s.tokens]
 
     def batch_n_fallbacks(self, utt: int) -> int: return self.L.wmi_batch_n_fallbacks(self.h, utt)
+    def batch_rc(self, utt: int) -> int: return self.L.wmi_batch_rc(self.h, utt)
     def batch_lang_id(self, utt: int) -> int: return self.L.wmi_batch_lang_id(self.h, utt)
 
     # -- low-level stages

@@ -24,7 +24,11 @@ WHISPER_API struct whisper_state *wmi_init_state_batch(struct whisper_context *c
 
 /* whisper_full semantics for n_utts utterances. samples[i] points to n_samples[i] floats
  * (16 kHz mono, [-1,1]) in HOST memory, or in DEVICE memory when samples_on_device != 0.
- * Returns 0 or the first failing utterance's whisper_full error code. */
+ * Returns 0 when the batch ran, whatever became of single utterances: an utterance that fails on its own (no language
+ * detected in a clip too short for it, no room left in the K/V page pool, ...) carries its whisper_full error code in
+ * wmi_batch_rc() and has no segments, and the others are unaffected -- as when Handy's callers each make their own
+ * transcribe call (reference: src-tauri/src/discord_conversation.rs:470-476). Non-zero: the batch as a whole failed
+ * (bad arguments, a HIP error, an abort callback). */
 WHISPER_API int wmi_full_batch(struct whisper_context *ctx, struct whisper_state *state, struct whisper_full_params params,
                                const float *const *samples, const int *n_samples, int n_utts, int samples_on_device);
 
@@ -37,6 +41,7 @@ WHISPER_API const char *wmi_batch_segment_text(struct whisper_state *state, int 
 WHISPER_API int wmi_batch_n_tokens(struct whisper_state *state, int utt, int seg);
 WHISPER_API whisper_token_data wmi_batch_token_data(struct whisper_state *state, int utt, int seg, int tok);
 WHISPER_API int wmi_batch_lang_id(struct whisper_state *state, int utt);
+WHISPER_API int wmi_batch_rc(struct whisper_state *state, int utt);        /* 0, or the whisper_full error code of this utterance */
 WHISPER_API int wmi_batch_n_fallbacks(struct whisper_state *state, int utt);
 
 /* Benchmark control (no upstream counterpart): when n > 0 every decoded sequence is exactly n

@@ -939,7 +939,7 @@ int wo_full(wo_state *s, const wo_params *pin, const float *pcm, int n) {
     if (p->strategy == 0) n_decoders = p->best_of; else n_decoders = p->best_of > p->beam_size ? p->best_of : p->beam_size;
     if (n_decoders < 1) n_decoders = 1;
     if (n_decoders > WO_MAX_DECODERS) return -4;
-    for (int j = 0; j < n_decoders; j++) { dec_alloc(s, j); rng_seed(&s->dec[j].rng, 0); }   /* [recalled] every decoder's mt19937 starts from seed 0 */
+    for (int j = 0; j < n_decoders; j++) { dec_alloc(s, j); rng_seed(&s->dec[j].rng, (uint32_t)j); }   /* decoder j's mt19937 starts from seed j [recalled]: with one shared seed the best_of decoders, which start from the same prompt logits, would all draw the same tokens */
 
     if (p->no_context) s->n_prompt_past = 0;
     if (p->prompt_tokens && p->prompt_n_tokens > 0) {

@@ -147,7 +147,8 @@ class _FakeEngine:
         time.sleep(0.02)                       # a batch in flight: later callers pile up behind it
         if any(a[0] < 0 for a in audios):
             raise ValueError("bad audio")
-        return [f"  text of {len(a)} samples \n" for a in audios]
+        # an utterance that fails on its own comes back as an exception in its slot
+        return [ValueError("bad clip") if a[0] == 9.0 else f"  text of {len(a)} samples \n" for a in audios]
 
     def close(self):
         self.closed = True
@@ -184,6 +185,17 @@ def test_transcription_manager_front_coalesces_calls():
     with pytest.raises(RuntimeError, match="Whisper transcription failed"):
         tm.transcribe(np.full(5, -1.0, np.float32))
     assert tm.transcribe(np.full(7, 1.0, np.float32)) == "text of 7 samples"
+    # one failing utterance inside a batch fails its own caller only
+    res = {}
+    def call2(i, v):
+        try:
+            res[i] = tm.transcribe(np.full(20 + i, v, np.float32))
+        except RuntimeError as e:
+            res[i] = e
+    th = [threading.Thread(target=call2, args=(i, 9.0 if i == 1 else 0.5)) for i in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert res[0] == "text of 20 samples" and res[2] == "text of 22 samples" and isinstance(res[1], RuntimeError)
     tm.unload_model()
     assert eng.closed and not tm.is_model_loaded()
     with pytest.raises(RuntimeError, match="Model is not loaded"):

@@ -365,3 +365,89 @@ def test_bad_model_files_fail_cleanly(wr, model_path, tmp_path):
             wr.WhisperContext(str(p))
     with pytest.raises(wr.WhisperError):
         wr.WhisperContext(str(tmp_path / "missing.bin"))
+
+
+def test_best_of_decoders_draw_different_sequences(wr, model_path):
+    """Temperature 0.8 without fallback: decoder j draws with its own generator, so the best of four sequences is, on some
+    clip at least, not the sequence the lone decoder of a best_of = 1 run draws (with one seed for all of them the four
+    would be copies of that one and best_of would buy nothing)."""
+    path = model_path("micro.en", decisive=1.0)
+    ctx = wr.WhisperContext(path)
+    pcms = [synth_pcm(500 + i, 6 * 16000) for i in range(6)]
+    out = {}
+    for k in (1, 4):
+        fp = wr.FullParams(wr.SamplingStrategy.Greedy(k))
+        fp.set_temperature(0.8); fp.set_temperature_inc(0.0); fp.set_language("en")
+        st = ctx.create_batch_state(len(pcms), 4, 4)
+        st.full_batch(fp, pcms)
+        out[k] = [st.batch_tokens(u) for u in range(len(pcms))]
+        st.full_batch(fp, pcms)
+        assert [st.batch_tokens(u) for u in range(len(pcms))] == out[k]          # the draws repeat run to run
+        st.free()
+    ctx.free()
+    assert all(len(t) > 0 for t in out[1])
+    assert sum(a != b for a, b in zip(out[1], out[4])) >= 1, "best_of = 4 returned the best_of = 1 sequences on every clip"
+
+
+def test_text_context_carries_over_between_calls(wr, oracle, model_path):
+    """no_context = false: the second whisper_full call of a state starts from the text the first one produced (the prompt
+    tokens of the call go in front of it), as in the oracle; no_context = true forgets it."""
+    path = model_path("micro", decisive=4.0)
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    ctx = wr.WhisperContext(path); st = ctx.create_state()
+    a, b = synth_pcm(600, 12 * 16000), synth_pcm(601, 9 * 16000)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language("en"); fp.set_no_context(False)
+    op = _oracle_params(oracle, fp)
+    outs = []
+    for pcm in (a, b, b):
+        st.full(fp, pcm)
+        got = st.batch_segments(0)
+        ref = ost.full(op, pcm)
+        assert _same(got, ref), ([g.tokens for g in got], [r["tokens"] for r in ref])
+        outs.append([g.tokens for g in got])
+    fp.set_no_context(True); op.no_context = 1
+    st.full(fp, b)
+    clean = [g.tokens for g in st.batch_segments(0)]
+    assert _same(st.batch_segments(0), ost.full(op, b))
+    assert clean != outs[1] or clean != outs[2], "the carried text context never changed a token"
+    st.free(); ctx.free(); ost.close(); om.close()
+
+
+def test_one_bad_utterance_does_not_fail_the_batch(wr, model_path):
+    """Language detection on a clip too short to hold a frame fails that utterance (code -3) -- and only that one: the others
+    in the batch return what they return alone. Out-of-vocabulary prompt tokens are rejected before anything runs."""
+    path = model_path("micro", decisive=4.0)
+    ctx = wr.WhisperContext(path)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language("auto")
+    pcms = [synth_pcm(700, 10 * 16000), synth_pcm(701, 30), synth_pcm(702, 5 * 16000)]
+    st = ctx.create_batch_state(3, 1, 2)
+    assert st.full_batch(fp, pcms) == 0
+    assert [st.batch_rc(u) for u in range(3)] == [0, -3, 0]
+    assert st.batch_tokens(1) == [] and len(st.batch_tokens(0)) > 0 and len(st.batch_tokens(2)) > 0
+    one = ctx.create_state()
+    for u in (0, 2):
+        one.full(fp, pcms[u])
+        assert one.batch_tokens(0) == st.batch_tokens(u)
+    with pytest.raises(wr.WhisperError):
+        one.full(fp, pcms[1])                       # the one-utterance call reports its utterance's failure
+    # the manager front hands the failure to the caller of that clip only
+    from handy_amd.manager import TranscriptionManager
+    import threading
+    tm = TranscriptionManager(max_batch=4, collect_ms=100.0, selected_language="auto")
+    tm.load_model(path)
+    res = [None] * 3
+    def call(i):
+        try: res[i] = tm.transcribe(pcms[i])
+        except RuntimeError as e: res[i] = e
+    th = [threading.Thread(target=call, args=(i,)) for i in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    tm.unload_model()
+    assert isinstance(res[1], RuntimeError) and isinstance(res[0], str) and isinstance(res[2], str)
+    fp2 = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp2.set_language("en"); fp2.set_tokens([5, 51865, 7])
+    with pytest.raises(wr.WhisperError):
+        st.full_batch(fp2, pcms)
+    fp2.set_tokens([5, -1])
+    with pytest.raises(wr.WhisperError):
+        st.full_batch(fp2, pcms)
+    st.free(); one.free(); ctx.free()

@@ -174,3 +174,27 @@ def test_encoder_decoder_parity(wr, oracle, golden, model_path, arch):
     inc = np.stack([st.decode([toks[i]], i) for i in range(4, 8)])
     assert np.abs(inc - lgot[4:8]).max() <= 2e-3
     st.free(); ctx.free(); ost.close(); om.close()
+
+
+@pytest.mark.parametrize("arch", ["mini", "mini512", "mini768"])
+def test_decoder_pass_at_full_row_capacity_small_widths(wr, oracle, model_path, arch):
+    """One decoder pass of 250 rows (a long prompt: nearly the 256 rows a default state holds) at tiny's, base's and small's
+    widths, where the QKV and fc1 projections go through split-K with 3d- and 4d-wide partial sums: logits against the
+    oracle. (The partial-sum workspace has to hold the widest of them at the state's full row count.)"""
+    path = model_path(arch)
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    ctx = wr.WhisperContext(path); st = ctx.create_state()
+    pcm = synth_pcm(9, 6 * 16000)
+    ost.pcm_to_mel(pcm); st.pcm_to_mel(pcm)
+    ost.encode(0); st.encode(0)
+    rng = np.random.default_rng(17)
+    toks = [om.special("sot")] + [int(t) for t in rng.integers(0, 50000, size=249)]
+    lref = ost.decode(toks, 0, 0, logits_all=True)
+    lgot = st.decode_logits_all(toks, 0)
+    err = float(np.abs(lgot - lref).max())
+    print(arch, "250-row pass: logits max abs err", err, "std", float(lref.std()))
+    assert err <= 1e-2, err
+    # and the cache it left behind serves the next position
+    nxt = st.decode([1234], 250)
+    assert float(np.abs(nxt - ost.decode([1234], 250, 0)[0]).max()) <= 1e-2
+    st.free(); ctx.free(); ost.close(); om.close()
