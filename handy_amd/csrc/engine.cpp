@@ -396,7 +396,7 @@ bool Engine::append_kv_slot(Decoder &d, int pos, std::vector<int2> &copies, int 
 
 // ------------------------------------------------------------------------------------------ decoder pass
 bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow> &srows, const std::vector<const Decoder *> &seqs,
-                          const std::vector<int2> &page_copies, int T, bool want_raw_logits_host, float *logits_all_out) {
+                          const std::vector<int2> &page_copies, int T, bool want_raw_logits_host, float *logits_all_out, const LogitsFilter *filter) {
     const int R = (int)rows.size(), L = (int)srows.size(), S = (int)seqs.size(), C = (int)page_copies.size(), d = d_;
     if (R <= 0) return true;
     const double t_pass0 = now_ms();
@@ -509,6 +509,22 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         TopkOut *d_topk = (TopkOut *)(out_dev_.as<char>() + sizeof(SampleOut) * lrows_cap_);
         bool any_extra = any_probs;
         for (const SampleRow &s : srows) any_extra |= s.topk > 0;
+        if (filter) {
+            // whisper_full hands the logits to the caller's filter after the temperature and the special-token suppression and
+            // applies the remaining rules to what the filter leaves: first half of the rules, rows to the host and back, second half
+            std::vector<SampleRow> half(srows);
+            for (SampleRow &r : half) r.flags |= 512;
+            filter_rows_.resize((size_t)L * V_);
+            WMI_HIP_OK(hipMemcpyAsync(meta_dev_.as<char>() + o_srow, half.data(), sizeof(SampleRow) * L, hipMemcpyHostToDevice, stream_));
+            if (!sample_rows(logits_.as<float>(), Vp_, L, d_srow, model->vocab_ids(), model->nst_bitmap, d_out, d_topk, 8, nullptr, false, sample_ws_.p, stream_)) return false;
+            WMI_HIP_OK(hipMemcpy2DAsync(filter_rows_.data(), sizeof(float) * V_, logits_.p, sizeof(float) * Vp_, sizeof(float) * V_, L, hipMemcpyDeviceToHost, stream_));
+            WMI_HIP_OK(hipStreamSynchronize(stream_));
+            for (int r = 0; r < L; r++) (*filter)(r, filter_rows_.data() + (size_t)r * V_);
+            for (SampleRow &r : half) r.flags = (r.flags & ~512) | 1024;
+            WMI_HIP_OK(hipMemcpy2DAsync(logits_.p, sizeof(float) * Vp_, filter_rows_.data(), sizeof(float) * V_, sizeof(float) * V_, L, hipMemcpyHostToDevice, stream_));
+            WMI_HIP_OK(hipMemcpyAsync(meta_dev_.as<char>() + o_srow, half.data(), sizeof(SampleRow) * L, hipMemcpyHostToDevice, stream_));
+            WMI_HIP_OK(hipStreamSynchronize(stream_));        // `half` leaves scope below; the copies above read pageable host memory
+        }
         PROF(WMI_K_DEC_OTHER, 8.0 * L * V_, sample_rows(logits_.as<float>(), Vp_, L, d_srow, model->vocab_ids(), model->nst_bitmap, d_out, d_topk, 8,
                                                        any_probs ? probs_.as<float>() : nullptr, any_extra, sample_ws_.p, stream_));
         WMI_HIP_OK(hipMemcpyAsync(out_host_.p, out_dev_.p, sizeof(SampleOut) * lrows_cap_ + sizeof(TopkOut) * 8 * (size_t)L, hipMemcpyDeviceToHost, stream_));
@@ -606,6 +622,7 @@ whisper_token_data make_token(int id, int tid, float p, float plog, float pt, fl
 }  // namespace
 
 struct Engine::Run {
+    using LogitsFilter = Engine::LogitsFilter;
     Engine &E;
     whisper_context *ctx; whisper_state *st;
     whisper_full_params P;
@@ -1160,7 +1177,15 @@ int Engine::Run::run_group(const float *const *pcm, const int *n, int g0, int G,
         }
         t0 = now_ms();
         const int T = E.enc_T_;
-        if (!E.decoder_pass(rows, srows, seqs, copies, T, false, nullptr)) { rc = -7; break; }
+        LogitsFilter filter;
+        if (P.logits_filter_callback)
+            filter = [&](int lr, float *logits) {
+                if (lref[lr].dec < 0) return;                                    // language detection row: no rules, no filter
+                const Utt &fu = utts[lref[lr].utt];
+                const std::vector<whisper_token_data> &tk = fu.dec[lref[lr].dec].seq.tokens;
+                P.logits_filter_callback(ctx, st, tk.data(), fu.phase == Phase::Prompt ? 0 : (int)tk.size(), logits, P.logits_filter_callback_user_data);
+            };
+        if (!E.decoder_pass(rows, srows, seqs, copies, T, false, nullptr, P.logits_filter_callback ? &filter : nullptr)) { rc = -7; break; }
         E.t_decode_ms += now_ms() - t0;
         const SampleOut *so = E.out_host_.as<SampleOut>();
         const TopkOut *tk = (const TopkOut *)(E.out_host_.as<char>() + sizeof(SampleOut) * E.lrows_cap_);

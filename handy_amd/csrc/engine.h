@@ -1,6 +1,7 @@
 // Batched whisper_full engine: per-utterance state machines on the host drive batched encoder
 // chunks and decoder passes on one GPU stream.
 #pragma once
+#include <functional>
 #include <random>
 #include <string>
 #include <deque>
@@ -184,6 +185,7 @@ private:
     DevBuf meta_dev_, out_dev_, sample_ws_, splitk_ws_;
     PinnedBuf meta_host_, out_host_, probs_host_;
     std::vector<float> logits_host_;
+    std::vector<float> filter_rows_;  // logit rows on the host while the caller's logits_filter_callback looks at them
     Decoder ll_dec_;                 // sequence used by whisper_decode()
     std::vector<int2> xgroups_;      // cross-attention row groups of the pass being built
 
@@ -200,8 +202,10 @@ private:
     bool compute_mel(const float *pcm_dev_base, const std::vector<long> &offs, const std::vector<int> &n);
     bool encode_chunk(const std::vector<WinDesc> &wins, const std::vector<int> &slots, int T, bool want_f32, hipStream_t s, int lane);
     struct PassOut { std::vector<SampleOut> so; std::vector<TopkOut> topk; };
+    // filter (optional): called per logit row with that row's logits in host memory, between the two halves of the rules
+    using LogitsFilter = std::function<void(int logit_row, float *logits)>;
     bool decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow> &srows, const std::vector<const Decoder *> &seqs,
-                      const std::vector<int2> &page_copies, int T, bool want_raw_logits_host, float *logits_all_out);
+                      const std::vector<int2> &page_copies, int T, bool want_raw_logits_host, float *logits_all_out, const LogitsFilter *filter = nullptr);
     // KV pages
     int page_alloc();
     void page_release(std::vector<int> &pages);

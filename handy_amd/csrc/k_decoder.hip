@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(float *__restrict__
     float *lg = logits + (long)r * ld;
     const int fl = sr.flags;
     const bool is_initial = fl & 1, last_ts = fl & 2, pen_ts = fl & 4, has_ts = fl & 8, sup_blank = fl & 16, no_ts = fl & 32,
-               sup_nst = fl & 64, tdrz = fl & 128, raw = fl & 256;
+               sup_nst = fl & 64, tdrz = fl & 128, raw = fl & 256, stage_a = fl & 512, stage_b = fl & 1024;
+    // stage_a / stage_b: the rules in two launches with a host callback on the logits in between (logits_filter_callback):
+    // the first applies the temperature and the special-token suppression, the second everything after them
     ArgMax mt = {-INFINITY, 0x7fffffff}, ms = {-INFINITY, 0x7fffffff};
     float val[kSamplePer];
 #pragma unroll
@@ -385,22 +387,26 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(float *__restrict__
         float v = -INFINITY;
         if (i < V) {
             v = lg[i];
-            if (sr.temperature > 0.0f) v = v / sr.temperature;
+            if (sr.temperature > 0.0f && !stage_b) v = v / sr.temperature;
             if (!raw) {
                 bool kill = false;
-                if (sup_blank && is_initial && (i == vi.eot || i == vi.space)) kill = true;
-                if (i == vi.tok_not || i == vi.sot || i == vi.nosp || i == vi.translate || i == vi.transcribe || i == vi.prev) kill = true;
-                if (i == vi.solm && !tdrz) kill = true;
-                if (no_ts && i >= vi.beg) kill = true;
-                if (i > vi.sot && i <= vi.sot + 100) kill = true;                       // language tokens
-                if (sup_nst && ((nst_bitmap[i >> 5] >> (i & 31)) & 1)) kill = true;
-                if (sr.force_n > 0) {
-                    if (sr.n_sampled < sr.force_n) { if (i == vi.eot) kill = true; }
-                    else { if (i != vi.eot) kill = true; else { kill = false; v = 0.0f; } }
+                if (!stage_b) {
+                    if (sup_blank && is_initial && (i == vi.eot || i == vi.space)) kill = true;
+                    if (i == vi.tok_not || i == vi.sot || i == vi.nosp || i == vi.translate || i == vi.transcribe || i == vi.prev) kill = true;
+                    if (i == vi.solm && !tdrz) kill = true;
+                    if (no_ts && i >= vi.beg) kill = true;
+                    if (i > vi.sot && i <= vi.sot + 100) kill = true;                       // language tokens
                 }
-                if (last_ts) { if (pen_ts) { if (i >= vi.beg) kill = true; } else if (i < vi.eot) kill = true; }
-                if (is_initial && sr.max_initial >= 0 && i > vi.beg + sr.max_initial) kill = true;
-                if (has_ts && i >= vi.beg && i < vi.beg + sr.ts_min) kill = true;
+                if (!stage_a) {
+                    if (sup_nst && ((nst_bitmap[i >> 5] >> (i & 31)) & 1)) kill = true;
+                    if (sr.force_n > 0) {
+                        if (sr.n_sampled < sr.force_n) { if (i == vi.eot) kill = true; }
+                        else { if (i != vi.eot) kill = true; else { kill = false; v = 0.0f; } }
+                    }
+                    if (last_ts) { if (pen_ts) { if (i >= vi.beg) kill = true; } else if (i < vi.eot) kill = true; }
+                    if (is_initial && sr.max_initial >= 0 && i > vi.beg + sr.max_initial) kill = true;
+                    if (has_ts && i >= vi.beg && i < vi.beg + sr.ts_min) kill = true;
+                }
                 if (kill) v = -INFINITY;
                 lg[i] = v;
             }

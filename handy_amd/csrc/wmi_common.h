@@ -57,6 +57,7 @@ struct SampleRow {
     int32_t flags;          // bit0 is_initial, bit1 last_was_ts, bit2 penultimate_was_ts, bit3 has_ts,
                             // bit4 suppress_blank, bit5 no_timestamps, bit6 suppress_nst, bit7 tdrz_enable,
                             // bit8 raw (no rules: used by whisper_decode / language detection)
+                            // bit9 / bit10: only the rules before / after the point where whisper_full calls logits_filter_callback
     int32_t ts_min;         // monotonic rule: timestamps below token_beg + ts_min are masked (has_ts)
     int32_t max_initial;    // first-position rule: timestamps above token_beg + max_initial masked; <0 off
     int32_t n_sampled;      // tokens sampled so far in this sequence

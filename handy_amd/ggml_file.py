@@ -295,10 +295,49 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.
     return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
 
 
-def synthetic_tensors(hp: HParams, seed: int = 0, decisive: float = 1.0) -> Iterable[Tuple[str, np.ndarray]]:
+def special_token_ids(n_vocab: int) -> Dict[str, int]:
+    """eot / sot / beg ... of a Whisper vocabulary of this size (English-only 51864, multilingual 51865, 51866)."""
+    if n_vocab < 51865:
+        return dict(eot=50256, sot=50257, translate=50357, transcribe=50358, solm=50359, prev=50360, nosp=50361, tok_not=50362, beg=50363)
+    dt = n_vocab - 51765 - 1 - 98
+    return dict(eot=50257, sot=50258, translate=50357 + dt, transcribe=50358 + dt, solm=50359 + dt, prev=50360 + dt, nosp=50361 + dt,
+                tok_not=50362 + dt, beg=50363 + dt)
+
+
+def synthetic_tensors(hp: HParams, seed: int = 0, decisive: float = 1.0, style: str = "plain") -> Iterable[Tuple[str, np.ndarray]]:
     """Seeded random weights sized so activations stay O(1) through the stack.
-    `decisive` scales the token embedding (hence the logits' spread)."""
+    `decisive` scales the token embedding (hence the logits' spread).
+    style "plain": every tensor an independent Gaussian. With the output projection tied to the token embedding, a decoded
+    token's own embedding then dominates the next step's logits and greedy decoding settles on one repeated token.
+    style "varied": the decoder's positional embedding and its attention outputs outweigh the token embedding, the cross-
+    attention is sharp, decoder biases are zero and the timestamp / end-of-text rows of the embedding are a little longer,
+    so that decoding walks through many different text tokens, timestamps and segment ends, and depends on the audio --
+    the control flow the whisper_full rules exist for. Test weights either way; nothing here resembles a trained model."""
     rng = np.random.default_rng(seed)
+    ids = special_token_ids(hp.n_vocab)
+    for name, w in _plain_tensors(hp, rng, decisive):
+        if style == "varied":
+            if name == "decoder.token_embedding.weight":
+                w = w.copy(); w[ids["beg"]:] *= 1.1; w[ids["eot"]] *= 2.0
+            elif name == "decoder.positional_embedding":
+                w = w * 30.0
+            elif name == "decoder.ln.bias":
+                w = w * 0.0
+            elif name.startswith("decoder.blocks."):
+                if name.endswith(".bias") and not name.endswith("_ln.bias"):
+                    w = w * 0.0
+                elif name.endswith("cross_attn.out.weight"):
+                    w = w * 6.0
+                elif name.endswith(".attn.out.weight"):
+                    w = w * 2.0
+                elif name.endswith("cross_attn.query.weight") or name.endswith("cross_attn.key.weight"):
+                    w = w * 4.0
+        elif style != "plain":
+            raise ValueError(f"unknown synthetic weight style {style!r}")
+        yield name, w.astype(np.float32)
+
+
+def _plain_tensors(hp: HParams, rng, decisive: float) -> Iterable[Tuple[str, np.ndarray]]:
     for name, shape in tensor_specs(hp):
         if name == "encoder.positional_embedding":
             w = sinusoids(shape[0], shape[1])
@@ -353,14 +392,14 @@ def n_file_tokens(hp: HParams) -> int:
 
 
 def write_synthetic_model(path: str, arch: str = "micro.en", seed: int = 0, ftype: int = 1,
-                          decisive: float = 1.0, hp: HParams | None = None, filters: np.ndarray | None = None) -> HParams:
-    """`filters` replaces the standard [n_mels, 201] mel table (tests of unusual tables)."""
+                          decisive: float = 1.0, hp: HParams | None = None, filters: np.ndarray | None = None, style: str = "plain") -> HParams:
+    """`filters` replaces the standard [n_mels, 201] mel table (tests of unusual tables); `style`: see synthetic_tensors."""
     hp = hp or hparams_for(arch, ftype)
     hp.ftype = ftype
     wtype = FTYPE_TO_TTYPE[ftype % 1000]
     with open(path, "wb") as f:
         write_header(f, hp, mel_filterbank(hp.n_mels) if filters is None else filters, synthetic_vocab(n_file_tokens(hp)))
-        for name, w in synthetic_tensors(hp, seed, decisive):
+        for name, w in synthetic_tensors(hp, seed, decisive, style):
             tt = T_F32 if _stays_f32(name, w.shape) else wtype
             if tt not in (T_F32, T_F16) and w.shape[-1] % BLOCK != 0:
                 tt = T_F16

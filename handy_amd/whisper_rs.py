@@ -86,6 +86,11 @@ class whisper_full_params(C.Structure):
     ]
 
 
+# callback types of whisper_full_params (include/whisper.h)
+LOGITS_FILTER_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(whisper_token_data), C.c_int, C.POINTER(C.c_float), C.c_void_p)
+ENCODER_BEGIN_CALLBACK = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
 class wmi_kernel_stat(C.Structure):
     _fields_ = [("ms", C.c_double), ("work", C.c_double), ("launches", C.c_longlong)]
 
@@ -266,6 +271,19 @@ class FullParams:
     def set_n_max_text_ctx(self, v: int): self.c.n_max_text_ctx = v
     def set_n_threads(self, v: int): self.c.n_threads = v
     def set_tdrz_enable(self, v: bool): self.c.tdrz_enable = v
+
+    def set_filter_logits_callback(self, fn):
+        """fn(tokens: list of whisper_token_data, logits: float32 array of n_vocab, writable) -- whisper_logits_filter_callback"""
+        def tramp(ctx, _state, tokens, n_tokens, logits, _ud):
+            n_vocab = load_library().whisper_n_vocab(ctx)
+            fn([tokens[i] for i in range(n_tokens)], np.ctypeslib.as_array(logits, shape=(n_vocab,)))
+        self._keep["logits_filter"] = LOGITS_FILTER_CALLBACK(tramp)
+        self.c.logits_filter_callback = C.cast(self._keep["logits_filter"], C.c_void_p)
+
+    def set_encoder_begin_callback(self, fn):
+        """fn() -> bool, called before each 30 s window is encoded; False ends the call with the segments so far"""
+        self._keep["encoder_begin"] = ENCODER_BEGIN_CALLBACK(lambda _c, _s, _u: bool(fn()))
+        self.c.encoder_begin_callback = C.cast(self._keep["encoder_begin"], C.c_void_p)
 
     def set_initial_prompt(self, s: str):
         self._keep["initial_prompt"] = s.encode()

@@ -141,7 +141,7 @@ struct whisper_full_params {
     void *encoder_begin_callback_user_data;
     ggml_abort_callback abort_callback;
     void *abort_callback_user_data;
-    whisper_logits_filter_callback logits_filter_callback;   /* accepted, ignored: logits stay on the device */
+    whisper_logits_filter_callback logits_filter_callback;   /* the logit rows make a round trip to host memory on every decoder pass while it is set */
     void *logits_filter_callback_user_data;
 
     const whisper_grammar_element **grammar_rules;           /* accepted, ignored */

@@ -27,7 +27,13 @@ class WoParams(C.Structure):
         ("no_speech_thold", C.c_float), ("best_of", C.c_int), ("beam_size", C.c_int),
         ("beam_candidates_topk", C.c_int), ("prompt_tokens", C.POINTER(C.c_int32)), ("prompt_n_tokens", C.c_int),
         ("force_n_tokens", C.c_int),
+        ("logits_filter_callback", C.c_void_p), ("logits_filter_callback_user_data", C.c_void_p),
+        ("encoder_begin_callback", C.c_void_p), ("encoder_begin_callback_user_data", C.c_void_p),
     ]
+
+
+LOGITS_FILTER = C.CFUNCTYPE(None, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float), C.c_void_p)
+ENCODER_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
 class WoTokenData(C.Structure):

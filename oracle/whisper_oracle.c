@@ -740,6 +740,7 @@ void wo_process_logits(const wo_model *m, const wo_params *p, const float *logit
     if (!p->tdrz_enable) logits[m->t_solm] = -INFINITY;
     logits[m->t_translate] = -INFINITY; logits[m->t_transcribe] = -INFINITY; logits[m->t_prev] = -INFINITY;
     for (int i = 0; i < 100; i++) { int t = token_lang(m, i); if (t < V) logits[t] = -INFINITY; }
+    if (p->logits_filter_callback) p->logits_filter_callback(cur, n_cur, logits, p->logits_filter_callback_user_data);
     if (p->suppress_nst) for (int i = 0; i < m->n_nst; i++) logits[m->nst_ids[i]] = -INFINITY;
     if (p->force_n_tokens > 0) {   /* benchmark control, not part of the upstream algorithm */
         if (n_cur < p->force_n_tokens) logits[m->t_eot] = -INFINITY;
@@ -975,6 +976,7 @@ int wo_full(wo_state *s, const wo_params *pin, const float *pcm, int n) {
 
     while (1) {
         if (seek + 100 >= seek_end) break;
+        if (p->encoder_begin_callback && !p->encoder_begin_callback(p->encoder_begin_callback_user_data)) break;
         if (wo_encode(s, seek, p->audio_ctx) != 0) { rc = -6; break; }
         if (seek > seek_start && seek + 500 >= seek_end) s->n_prompt_past = 0;
         int best_id = 0;

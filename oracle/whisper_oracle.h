@@ -43,6 +43,15 @@ typedef struct wo_params {
     int   beam_candidates_topk; /* 0: candidates drawn from the distribution (upstream), 1: deterministic top-k */
     const int32_t *prompt_tokens; int prompt_n_tokens;
     int   force_n_tokens;    /* benchmark control: >0 => suppress EOT before, force EOT at, this many sampled tokens */
+    /* whisper_full_params.logits_filter_callback [recalled]: called on every decoder's logits after the temperature and the
+     * special-token suppression, before the non-speech list and the timestamp rules; may rewrite the logits in place.
+     * (upstream also passes ctx and state, and the tokens as whisper_token_data; here: the token ids sampled so far) */
+    void (*logits_filter_callback)(const int32_t *tokens, int n_tokens, float *logits, void *user_data);
+    void *logits_filter_callback_user_data;
+    /* whisper_full_params.encoder_begin_callback [recalled]: called before each window is encoded; returning 0 ends the
+     * call with the segments produced so far */
+    int  (*encoder_begin_callback)(void *user_data);
+    void *encoder_begin_callback_user_data;
 } wo_params;
 
 typedef struct wo_token_data {

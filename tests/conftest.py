@@ -24,11 +24,11 @@ def model_path(model_dir):
     from handy_amd import ggml_file as gf
     cache = {}
 
-    def get(arch="micro.en", seed=0, ftype=1, decisive=1.0):
-        key = (arch, seed, ftype, decisive)
+    def get(arch="micro.en", seed=0, ftype=1, decisive=1.0, style="plain"):
+        key = (arch, seed, ftype, decisive, style)
         if key not in cache:
-            p = os.path.join(model_dir, f"{arch}_s{seed}_f{ftype}_d{decisive}.bin")
-            gf.write_synthetic_model(p, arch, seed=seed, ftype=ftype, decisive=decisive)
+            p = os.path.join(model_dir, f"{arch}_s{seed}_f{ftype}_d{decisive}_{style}.bin")
+            gf.write_synthetic_model(p, arch, seed=seed, ftype=ftype, decisive=decisive, style=style)
             cache[key] = p
         return cache[key]
 
