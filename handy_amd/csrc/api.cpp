@@ -79,6 +79,9 @@ struct whisper_context *whisper_init_from_buffer_with_params_no_state(void *buff
     if (!m) return nullptr;
     whisper_context *ctx = new whisper_context();
     ctx->model = m; ctx->params = params; ctx->t_load_ms = now_ms() - t0;
+    // set-up for wmi_pcm_to_mel_device_noalloc on this device (load_model left it current); a failure is reported by
+    // that entry point, which tries once more
+    (void)wmi::mel_noalloc_init(params.gpu_device);
     return ctx;
     WMI_CATCH(nullptr)
 }
@@ -349,6 +352,13 @@ int wmi_mel_batch_device(struct whisper_context *, struct whisper_state *s, cons
     WMI_TRY
     Engine *e = ENG(s); if (!e || !pcm_dev || !offsets || !n || B <= 0) return -1;
     return e->mel_batch_device(pcm_dev, offsets, n, B);
+    WMI_CATCH(-1)
+}
+int wmi_pcm_to_mel_device_noalloc(struct whisper_context *ctx, const float *pcm_dev, int n_samples, float *mel_out_dev, int n_frames_out, void *stream) {
+    WMI_TRY
+    if (!ctx || !ctx->model) return -1;
+    if (hipSetDevice(ctx->model->device) != hipSuccess) return -1;
+    return wmi::mel_noalloc(pcm_dev, n_samples, ctx->model->mel, mel_out_dev, n_frames_out, ctx->model->device, (hipStream_t)stream);
     WMI_CATCH(-1)
 }
 int wmi_get_mel(struct whisper_state *s, int utt, float *out, int n_frames) {

@@ -20,6 +20,8 @@
 // Bound: HBM. Algorithmic bytes per 30 s utterance: 480000*4 in + n_mel*3000*4 out.
 #include "kernels.h"
 
+#include <mutex>
+
 namespace wmi {
 
 constexpr int F = kMelFramesPerBlock;          // frames per workgroup
@@ -100,15 +102,17 @@ constexpr int kMaxPackedFilter = 1024;         // nonzero-support weights staged
 
 // PACKED: the filterbank's nonzero supports, concatenated, sit in LDS (meta word per mel bin: lo | count << 8 | offset << 16);
 // otherwise (a model file with a dense or very wide table) the weights are read from the dense table in global memory.
+// The utterance descriptors come from `utts` (one per blockIdx.y) or, when that is null, from the kernel argument `single`
+// (a launch for one utterance then needs no descriptor in device memory).
 template <bool PACKED>
-__global__ __launch_bounds__(256) void mel_raw_kernel(const float *__restrict__ pcm, const MelUtt *__restrict__ utts, MelTables tb,
+__global__ __launch_bounds__(256) void mel_raw_kernel(const float *__restrict__ pcm, const MelUtt *__restrict__ utts, MelUtt single, MelTables tb,
                                                       float *__restrict__ mel_out, unsigned *__restrict__ mel_max) {
     __shared__ __align__(16) float smp[NSR * 256];
     __shared__ float2 z[F * ZS];
     __shared__ float fw[PACKED ? kMaxPackedFilter : 1];
     __shared__ int fmeta[PACKED ? 128 : 1];
     __shared__ float wmax[4];
-    const MelUtt u = utts[blockIdx.y];
+    const MelUtt u = utts ? utts[blockIdx.y] : single;
     const int f0 = blockIdx.x * F;
     if (f0 >= u.n_frames) return;
     const int tid = threadIdx.x;
@@ -252,8 +256,8 @@ bool mel_raw(const float *pcm, const MelUtt *utts, int n_utt, int max_blocks_per
     if (n_utt <= 0 || max_blocks_per_utt <= 0) return true;
     WMI_HIP_OK(hipMemsetAsync(mel_max, 0, sizeof(unsigned) * n_utt, st));
     if (tb.n_mel > 128) return false;
-    if (tb.fpacked) hipLaunchKernelGGL(mel_raw_kernel<true>, dim3(max_blocks_per_utt, n_utt), dim3(256), 0, st, pcm, utts, tb, mel_raw_out, mel_max);
-    else hipLaunchKernelGGL(mel_raw_kernel<false>, dim3(max_blocks_per_utt, n_utt), dim3(256), 0, st, pcm, utts, tb, mel_raw_out, mel_max);
+    if (tb.fpacked) hipLaunchKernelGGL(mel_raw_kernel<true>, dim3(max_blocks_per_utt, n_utt), dim3(256), 0, st, pcm, utts, MelUtt{}, tb, mel_raw_out, mel_max);
+    else hipLaunchKernelGGL(mel_raw_kernel<false>, dim3(max_blocks_per_utt, n_utt), dim3(256), 0, st, pcm, utts, MelUtt{}, tb, mel_raw_out, mel_max);
     return hipGetLastError() == hipSuccess;
 }
 
@@ -280,6 +284,62 @@ bool mel_normalize(const float *raw, int n_mel, int n_frames, const unsigned *me
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(mel_normalize_kernel, dim3(blocks), dim3(256), 0, st, raw, n_mel, n_frames, mel_max, out, n_out);
     return hipGetLastError() == hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------ log-mel without allocations
+// The frontend for callers that may not allocate (code under HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc): one utterance of at most kMelNoAllocMaxSamples samples, PCM and result in the caller's device memory. What
+// the two kernels hand to each other -- the raw log-mel and the utterance maximum, which the library's other entry
+// points keep in buffers they allocate -- sits in a fixed array of this code object instead. Every GPU the library runs
+// on holds its own copy of the array at its own address until the process ends; the array's name is only a host-side
+// handle, so the device address is looked up once per device (that device current) and the kernels get the pointer as
+// an argument. The array keeps the previous call's contents: the maximum is cleared per call, the raw log-mel is only
+// read where this call wrote it. Calls that overlap on one GPU would share the array and race.
+constexpr int kMelNoAllocMaxFrames = ((kMelNoAllocMaxSamples + kNFft / 2) / kHop + 1 + F - 1) / F * F;      // 3008 for 30 s
+constexpr size_t kMelScratchHeader = 256;                                                                    // [0, 4): the utterance maximum
+constexpr size_t kMelScratchBytes = kMelScratchHeader + (size_t)128 * kMelNoAllocMaxFrames * sizeof(float);  // 1 540 352 bytes
+static __device__ __align__(256) unsigned char scratch[kMelScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static unsigned char *g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mu;
+
+// `device` must be the current device.
+bool mel_noalloc_init(int device) {
+    if (device < 0 || device >= kMaxDevices) return false;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[device]) return true;
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) { log_msg(2, "mel_noalloc_init: hipGetSymbolAddress failed on device %d: %s\n", device, hipGetErrorString(e)); return false; }
+    g_scratch_ptr[device] = (unsigned char *)p;
+    return true;
+}
+
+// pcm_dev[n] -> out_dev[n_mel][n_out] (normalised log-mel, frames past the audio carry the floor value). `device` is current.
+// Launches two kernels and one 256-byte memset on `st`; allocates nothing.
+int mel_noalloc(const float *pcm_dev, int n, const MelTables &tb, float *out_dev, int n_out, int device, hipStream_t st) {
+    if (!pcm_dev || !out_dev || n < 0 || n_out <= 0 || tb.n_mel <= 0 || tb.n_mel > 128) return -1;
+    if (n > kMelNoAllocMaxSamples || n_out > kMelNoAllocMaxFramesOut) {
+        log_msg(2, "wmi_pcm_to_mel_device_noalloc: %d samples / %d frames exceed the entry point's maximum of %d samples / %d frames\n", n, n_out, kMelNoAllocMaxSamples, kMelNoAllocMaxFramesOut);
+        return -2;
+    }
+    if (device < 0 || device >= kMaxDevices || (!g_scratch_ptr[device] && !mel_noalloc_init(device))) return -3;
+    unsigned char *ptr = g_scratch_ptr[device];
+    unsigned *mel_max = (unsigned *)ptr;
+    float *raw = (float *)(ptr + kMelScratchHeader);
+    MelUtt u{};
+    u.pcm_off = 0; u.n = n; u.mel_off = 0;
+    const int n_len = (n + kSampleRate * kChunkSec) / kHop;
+    u.n_calc = (n + kNFft / 2) / kHop + 1; if (u.n_calc > n_len) u.n_calc = n_len;
+    u.n_frames = (u.n_calc + F - 1) / F * F;
+    if (u.n_frames > kMelNoAllocMaxFrames) return -2;
+    if (hipMemsetAsync(ptr, 0, kMelScratchHeader, st) != hipSuccess) return -4;
+    if (tb.fpacked) hipLaunchKernelGGL(mel_raw_kernel<true>, dim3(u.n_frames / F, 1), dim3(256), 0, st, pcm_dev, (const MelUtt *)nullptr, u, tb, raw, mel_max);
+    else hipLaunchKernelGGL(mel_raw_kernel<false>, dim3(u.n_frames / F, 1), dim3(256), 0, st, pcm_dev, (const MelUtt *)nullptr, u, tb, raw, mel_max);
+    if (hipGetLastError() != hipSuccess) return -4;
+    if (!mel_normalize(raw, tb.n_mel, u.n_frames, mel_max, out_dev, n_out, st)) return -4;
+    return 0;
 }
 
 // window extraction + normalisation + transpose to [frame][mel] fp16 (the conv1 operand layout)

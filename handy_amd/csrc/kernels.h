@@ -55,6 +55,14 @@ constexpr int kMelFramesPerBlock = 32;
 bool mel_raw(const float *pcm, const MelUtt *utts, int n_utt, int max_blocks_per_utt, const MelTables &tb, float *mel_raw, unsigned *mel_max, hipStream_t st);
 // normalised copy: out[j][i] for i < n_out frames (clamp to max-8, (x+4)/4); frames past n_frames read as -10
 bool mel_normalize(const float *raw, int n_mel, int n_frames, const unsigned *mel_max, float *out, int n_out, hipStream_t st);
+// The same frontend for one utterance without any allocation (PCM and result in the caller's device memory, the kernels'
+// intermediate data in a fixed device array of the library): at most kMelNoAllocMaxSamples samples in, n_out <=
+// kMelNoAllocMaxFramesOut frames out. mel_noalloc_init looks the array's device address up (once per device, that device
+// current); mel_noalloc returns 0, -2 for sizes beyond the maximum, another negative code on failure.
+constexpr int kMelNoAllocMaxSamples = kSampleRate * kChunkSec;                        // 30 s
+constexpr int kMelNoAllocMaxFramesOut = 2 * kSampleRate * kChunkSec / kHop;           // 6000: the padded length of a 30 s clip
+bool mel_noalloc_init(int device);
+int mel_noalloc(const float *pcm_dev, int n, const MelTables &tb, float *out_dev, int n_out, int device, hipStream_t st);
 // encoder input windows: for chunk entry e, frames [seek[e], seek[e]+2T) of utterance utt[e] -> fp16 [e*(2T+2)+1+t][n_mel]
 struct WinDesc { long mel_off; int n_frames; int n_len; int seek; int max_idx; };
 bool mel_window(const float *raw, const unsigned *mel_max, const WinDesc *wins, int n_win, int n_mel, int T2, f16 *melT, hipStream_t st);

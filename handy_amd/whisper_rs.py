@@ -121,7 +121,7 @@ whisper_full_get_token_text whisper_full_get_token_text_from_state whisper_full_
 whisper_full_get_token_data whisper_full_get_token_data_from_state whisper_full_get_token_p whisper_full_get_token_p_from_state
 wmi_init_state_batch wmi_full_batch wmi_batch_n_utts wmi_batch_n_segments wmi_batch_segment_t0 wmi_batch_segment_t1
 wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks wmi_batch_rc
-wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
+wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_pcm_to_mel_device_noalloc wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
 wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_version
 """.split()
 
@@ -191,6 +191,7 @@ def load_library(path: Optional[str] = None):
     L.wmi_batch_rc.restype = ci; L.wmi_batch_rc.argtypes = [vp, ci]
     L.wmi_set_force_tokens.argtypes = [vp, ci]; L.wmi_set_beam_candidates_sampled.argtypes = [vp, ci]
     L.wmi_mel_batch_device.restype = ci; L.wmi_mel_batch_device.argtypes = [vp, vp, vp, C.POINTER(C.c_longlong), C.POINTER(ci), ci]
+    L.wmi_pcm_to_mel_device_noalloc.restype = ci; L.wmi_pcm_to_mel_device_noalloc.argtypes = [vp, vp, ci, vp, ci, vp]
     L.wmi_get_mel.restype = ci; L.wmi_get_mel.argtypes = [vp, ci, fp, ci]
     L.wmi_get_encoder_output.restype = ci; L.wmi_get_encoder_output.argtypes = [vp, fp]
     L.wmi_get_cross_kv.restype = ci; L.wmi_get_cross_kv.argtypes = [vp, ci, fp, fp]
@@ -337,6 +338,10 @@ class WhisperContext:
         if not h:
             raise WhisperError("InitError")
         return WhisperState(self, h)
+
+    def pcm_to_mel_device_noalloc(self, pcm_dev_ptr: int, n_samples: int, out_dev_ptr: int, n_frames_out: int, stream: int = 0) -> int:
+        """wmi_pcm_to_mel_device_noalloc: device pointers in, work enqueued on `stream`, nothing allocated; returns the C code."""
+        return self.L.wmi_pcm_to_mel_device_noalloc(self.h, pcm_dev_ptr, n_samples, out_dev_ptr, n_frames_out, stream or None)
 
     def n_vocab(self): return self.L.whisper_n_vocab(self.h)
     def n_text_ctx(self): return self.L.whisper_n_text_ctx(self.h)

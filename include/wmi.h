@@ -72,6 +72,18 @@ WHISPER_API void wmi_set_beam_candidates_sampled(struct whisper_state *state, in
 WHISPER_API int wmi_mel_batch_device(struct whisper_context *ctx, struct whisper_state *state, const float *pcm_dev,
                                      const long long *offsets, const int *n_samples, int n_utts);
 
+/* The log-mel frontend for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc). No counterpart in the reference: it is whisper_pcm_to_mel_with_state() followed by
+ * wmi_get_mel(), with the PCM (n_samples floats) and the result (normalised log-mel, [n_mel][n_frames_out] floats, frames
+ * past the audio at the floor value) both in the CALLER's device memory on the context's GPU, and the kernels'
+ * intermediate data in a fixed 1.5 MB device array of the library instead of buffers it would allocate. It calls no
+ * hipMalloc / hipFree or other allocating routine: it enqueues one 256-byte memset and two kernels on `stream` (a
+ * hipStream_t, or NULL for the null stream) and returns without waiting for them.
+ * Limits: n_samples <= 480000 (30 s) and n_frames_out <= 6000; beyond them the call returns -2 and does nothing.
+ * Every call on a GPU uses that GPU's one array: calls that may overlap on one GPU (two streams, two threads) race. */
+WHISPER_API int wmi_pcm_to_mel_device_noalloc(struct whisper_context *ctx, const float *pcm_dev, int n_samples, float *mel_out_dev,
+                                              int n_frames_out, void *stream);
+
 /* Inspection hooks used by the parity tests (all copy to host memory). */
 WHISPER_API int wmi_get_mel(struct whisper_state *state, int utt, float *out, int n_frames);          /* normalised [n_mel][n_frames] */
 WHISPER_API int wmi_get_encoder_output(struct whisper_state *state, float *out);                       /* last whisper_encode: [n_ctx][n_state] */
