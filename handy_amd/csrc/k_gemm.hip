@@ -333,8 +333,22 @@ __device__ __forceinline__ void write_tile(const Epi &epi, f32x4 (&acc)[TN][TM],
 // 8-lane write groups and the 16-lane read groups), and is then stored to memory as whole rows: one wave
 // instruction = 2 rows x 512 contiguous bytes. Direct stores from the accumulator layout touch 32 bytes per
 // row and instruction, which the memory side counts (and moves) as half-used 64-byte requests.
-template <class Epi, int XB = 0>          // XB (harness): 1 = no global stores, 2 = no LDS round trip (stores of the raw pairs, wrong values)
-__device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, int wr, int wc, int wave, int lane, char *smem) {
+// Which rows / columns of the 256 x 256 workgroup tile a wave's accumulator tiles acc[i][j] (i: 4 column tiles, j: 8 row
+// tiles of 16) cover. MapBlock: one 128 x 64 block per wave (2 x 4 waves). MapSplit: four 64 x 32 blocks, one in each
+// quarter of the tile -- the layout of the 8-phase kernel, whose waves take their operands from all four half-tiles.
+struct MapBlock {
+    int wr, wc;
+    __device__ __forceinline__ int row(int j) const { return wr * 128 + j * 16; }
+    __device__ __forceinline__ int col(int i) const { return wc * 64 + i * 16; }
+};
+struct MapSplit {
+    int wr, wc;
+    __device__ __forceinline__ int row(int j) const { return (j >> 2) * 128 + wr * 64 + (j & 3) * 16; }
+    __device__ __forceinline__ int col(int i) const { return (i >> 1) * 128 + wc * 32 + (i & 1) * 16; }
+};
+
+template <class Epi, int XB = 0, class Map = MapBlock>          // XB (harness): 1 = no global stores, 2 = no LDS round trip (stores of the raw pairs, wrong values)
+__device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, Map map, int wave, int lane, char *smem) {
     const int fr = lane & 15, fq = lane >> 4;
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): my last fragment reads are done
     __builtin_amdgcn_s_barrier();                // ... and everybody else's: the stage buffers are free
@@ -342,7 +356,7 @@ __device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
-            const int rx = wr * 128 + j * 16 + fr, ry = rx + 16, cn = wc * 64 + i * 16;
+            const int rx = map.row(j) + fr, ry = rx + 16, cn = map.col(i);
             union { f16x4 h; unsigned u[2]; } x, y;
             x.h = epi.value(m0 + rx, n0 + cn + fq * 4, acc[i][j]);
             y.h = epi.value(m0 + ry, n0 + cn + fq * 4, acc[i][j + 1]);
@@ -371,8 +385,8 @@ __device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4
 // An epilogue that adds to what the output already holds has its 16 rows per wave and half requested before the
 // accumulators go to LDS; the barriers here are the raw s_barrier after an LDS-only wait, so those requests stay in
 // flight across them (a __syncthreads() waits for every outstanding load).
-template <class Epi>
-__device__ __forceinline__ void write_tile_staged_f32(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, int wr, int wc, int wave, int lane, char *smem) {
+template <class Epi, class Map = MapBlock>
+__device__ __forceinline__ void write_tile_staged_f32(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, Map map, int wave, int lane, char *smem) {
     const int fr = lane & 15, fq = lane >> 4;
     constexpr bool RMW = reads_output<Epi>::value;
     f32x4 old[RMW ? 16 : 1];
@@ -391,14 +405,14 @@ __device__ __forceinline__ void write_tile_staged_f32(const Epi &epi, f32x4 (&ac
     lds_barrier();                               // everybody's last fragment reads are done: the stage buffers are free
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
-        if (wr == hh) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 8; j++) {
+            if ((map.row(j) >> 7) != hh) continue;           // this row tile lies in the other 128-row half
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int row = j * 16 + fr, chunk = wc * 16 + i * 4 + fq;
-                    *(f32x4 *)(smem + row * 1024 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
-                }
+            for (int i = 0; i < 4; i++) {
+                const int row = (map.row(j) & 127) + fr, chunk = (map.col(i) >> 2) + fq;
+                *(f32x4 *)(smem + row * 1024 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
+            }
         }
         lds_barrier();
 #pragma unroll
@@ -424,7 +438,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // groups instead of in one burst after the barrier; kFirstHalf confines that to the first k-half of the step,
 // so the loads get the second half's MFMAs as extra time to land. Harness-only builds: kNoLoads / kNoLdsReads /
 // kNoMfma drop one ingredient of the loop (ablation timing), kStamps records s_memtime per loop section.
-enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
+enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128, kNoStagger = 256, kIssueFirst = 512 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
@@ -553,10 +567,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
     }
     if constexpr (has_begin_tile<Epi>::value) epi.begin_tile(m0, n0);       // every tile shape is at most 256 x 256
     if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && Epi::kWide) {
-        if (epi.wide_block(n0, BN)) write_tile_staged<Epi, (ABL >> 8) & 3>(epi, acc, M, m0, n0, wr, wc, wave, lane, smem);
+        if (epi.wide_block(n0, BN)) write_tile_staged<Epi, (ABL >> 8) & 3>(epi, acc, M, m0, n0, MapBlock{wr, wc}, wave, lane, smem);
         else write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
     } else if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && !is_splitk<Epi>::value) {
-        write_tile_staged_f32(epi, acc, M, m0, n0, wr, wc, wave, lane, smem);
+        write_tile_staged_f32(epi, acc, M, m0, n0, MapBlock{wr, wc}, wave, lane, smem);
     } else {
         write_tile<TM, TN>(epi, acc, M, m0 + wr * (BM / WM), n0 + wc * (BN / WN), lane);
     }
@@ -569,6 +583,172 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
             o[0] = t_wait; o[1] = t_bar; o[2] = t_comp; o[3] = nk; o[4] = t_start; o[5] = t_pro; o[6] = t_issue - t_prev; o[7] = t_end;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ 8-phase kernel
+// 256 x 256 output tile, 8 waves, K in steps of 64 -- the same tile as above with the K-step cut into four phases of 16 MFMAs
+// and the two waves of each SIMD running half a phase apart, so that while one multiplies, the other reads its fragments
+// and issues its share of the LDS-DMA; the matrix pipe of a SIMD then sees one wave's MFMAs after the other's, back to back.
+//   * Each operand tile of a K-step is two half-tiles of 128 rows x 128 B (activation rows 0-127 "AL" / 128-255 "AH", weight
+//     rows "BL" / "BH"); LDS holds 8 half-tile slots (two K-steps). A wave owns a 64 x 32 block in each quarter of the
+//     output tile: rows wr*64.. of AL and of AH, columns wc*32.. of BL and of BH. Per K-step it reads BL + AL fragments
+//     (phase 0), BH (1), AH (2), nothing (3; the BL fragments are still in registers) and multiplies one quarter per phase.
+//     A slot is therefore free again two phases after the phase that read it, long before the K-step is over.
+//   * The stream of half-tiles AL, BL, BH, AH of K-step 0, 1, ... is issued one per phase, six ahead: phase p issues index
+//     p + 6 into the slot whose last reader was phase <= p + 4 - 6 ... i.e. at least two phases (four barriers) back.
+//   * After issuing, a wave waits for all but its 8 youngest LDS-DMA instructions (4 half-tiles in flight): everything up
+//     to index p + 2 has landed, which is all phase p + 1 reads. The barrier between the wait and the read publishes the
+//     other waves' pieces. Counted vmcnt, raw s_barrier: nothing in the loop drains the queue.
+//   * Waves 4-7 start one barrier late and waves 0-3 pass one extra barrier at the end; every barrier is still passed
+//     by all eight waves.
+// Accumulation order along K is the same as in gemm_nt_kernel: results are bit-identical.
+template <class Epi, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_nt8_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
+                                                       int M, int N, int K, int gm, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLOT = 128 * 128;                        // bytes of one half-tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int bm, bn;
+    tile_coords(blockIdx.x, (M + 255) / 256, N / 256, gm, bm, bn);
+    const int m0 = bm * 256, n0 = bn * 256;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    // staging: half-tile = 16 pieces of 8 rows x 128 B; wave w moves pieces w and w + 8 (rows 8w.. and 64 + 8w..)
+    const int srow = lane >> 3, sslot = lane & 7;
+    const f16 *a_src = A + (long)(m0 + wave * 8 + srow) * lda + ((sslot ^ srow) << 3);
+    const f16 *w_src = W + (long)(n0 + wave * 8 + srow) * ldw + ((sslot ^ srow) << 3);
+    const int nk = K / BK, total = 4 * nk;
+    auto issue = [&](int q) {          // q = 4 * K-step + {0 AL, 1 BL, 2 BH, 3 AH}
+        const int kt = q >> 2, h = q & 3;
+        char *dst = smem + (((kt & 1) << 2) + h) * SLOT + wave * 1024;
+        const bool is_a = h == 0 || h == 3;
+        const f16 *src = (is_a ? a_src : w_src) + (long)(h >= 2 ? 128 : 0) * (is_a ? lda : ldw) + (long)kt * BK;
+        const long step = 64 * (is_a ? lda : ldw);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + step), (__attribute__((address_space(3))) void *)(dst + 8192), 16, 0, 0);
+    };
+    // all but the n youngest LDS-DMA instructions of this wave have landed
+    auto wait_dma = [&](int halves_in_flight) {
+        if (halves_in_flight >= 4) wait_vmcnt<8>();
+        else if (halves_in_flight == 3) wait_vmcnt<6>();
+        else if (halves_in_flight == 2) wait_vmcnt<4>();
+        else if (halves_in_flight == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment addresses inside a slot: row (wave block + tile + fr), 16-byte chunk (ks * 4 + fq) ^ (row & 7); row & 7 == fr & 7
+    const int a_off = (wr * 64 + fr) * 128, b_off = (wc * 32 + fr) * 128;
+    const int c0 = ((fq) ^ (fr & 7)) << 4, c1 = ((4 + fq) ^ (fr & 7)) << 4;
+    f16x8 fa[4][2], fbl[2][2], fbh[2][2];
+    auto read_a = [&](const char *slot) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { fa[j][0] = *(const f16x8 *)(slot + a_off + j * 2048 + c0); fa[j][1] = *(const f16x8 *)(slot + a_off + j * 2048 + c1); }
+    };
+    auto read_b = [&](const char *slot, f16x8 (&fb)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) { fb[i][0] = *(const f16x8 *)(slot + b_off + i * 2048 + c0); fb[i][1] = *(const f16x8 *)(slot + b_off + i * 2048 + c1); }
+    };
+    auto mma = [&](const f16x8 (&fb)[2][2], int ib, int jb) {      // quarter (column half ib, row half jb)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[ib * 2 + i][jb * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[i][ks], fa[j][ks], acc[ib * 2 + i][jb * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: six half-tiles in flight, the first two landed
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        if (q < total) issue(q);
+    wait_dma(min(4, total - 2));
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1 && !(ABL & kNoStagger)) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind
+
+    // ABL & kStamps (harness): cycles per section, summed over the loop: [0] read segment up to the wait, [1] the DMA wait,
+    // [2] first barrier, [3] multiply segment, [4] second barrier
+    unsigned long long tsec[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int sec) {
+        if (ABL & kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tsec[sec] += t - tprev; tprev = t; }
+    };
+    if (ABL & kStamps) tprev = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt < nk; kt++) {
+        const char *sb = smem + ((kt & 1) << 2) * SLOT;            // slots AL, BL, BH, AH of this K-step
+        const int p = 4 * kt;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // ---- read segment
+            if ((ABL & kIssueFirst) && p + r + 6 < total) { issue(p + r + 6); __builtin_amdgcn_sched_barrier(0); }
+            if (r == 0) { read_b(sb + SLOT, fbl); __builtin_amdgcn_sched_barrier(0); read_a(sb); }
+            else if (r == 1) read_b(sb + 2 * SLOT, fbh);
+            else if (r == 2) read_a(sb + 3 * SLOT);
+            if (!(ABL & kIssueFirst) && p + r + 6 < total) issue(p + r + 6);
+            stamp(0);
+            wait_dma(total - 3 - (p + r));                          // indices <= p + r + 2 have landed
+            stamp(1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            stamp(2);
+            // ---- multiply segment
+            if (r == 0) mma(fbl, 0, 0);
+            else if (r == 1) mma(fbh, 1, 0);
+            else if (r == 2) mma(fbh, 1, 1);
+            else mma(fbl, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(3);
+            __builtin_amdgcn_s_barrier();
+            stamp(4);
+        }
+    }
+    if (wr == 0 && !(ABL & kNoStagger)) __builtin_amdgcn_s_barrier();  // the barrier waves 4-7 passed at the start
+    if ((ABL & kStamps) && lane == 0 && (int)blockIdx.x >= max(0, (int)gridDim.x - 2048)) {
+        unsigned long long *o = g_gemm_stamps + ((long)((int)blockIdx.x - max(0, (int)gridDim.x - 2048)) * 8 + wave) * 8;
+        o[0] = tsec[0]; o[1] = tsec[1]; o[2] = tsec[2]; o[3] = nk; o[4] = tsec[3]; o[5] = tsec[4]; o[6] = 0; o[7] = 0;
+    }
+
+    if constexpr (has_begin_tile<Epi>::value) epi.begin_tile(m0, n0);
+    const MapSplit map{wr, wc};
+    if constexpr (Epi::kWide) {
+        if (epi.wide_block(n0, 256)) { write_tile_staged<Epi, 0, MapSplit>(epi, acc, M, m0, n0, map, wave, lane, smem); return; }
+    } else if constexpr (!is_splitk<Epi>::value) {
+        write_tile_staged_f32<Epi, MapSplit>(epi, acc, M, m0, n0, map, wave, lane, smem);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int m = m0 + map.row(j) + fr;
+            if (m < M) epi(m, n0 + map.col(i) + fq * 4, acc[i][j]);
+        }
+}
+
+template <class Epi, int ABL = 0>
+static bool launch8(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int group_rows = 0) {
+    if (M <= 0) return true;
+    if (N % 256 != 0 || K % BK != 0 || K < 2 * BK) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (8-phase tile)\n", M, N, K); return false; }
+    const int nblk = ((M + 255) / 256) * (N / 256);
+    constexpr size_t lds = 8 * 128 * 128;
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        if (hipFuncSetAttribute((const void *)gemm_nt8_kernel<Epi, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        attr_set.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    const int nbn = N / 256, gm = group_rows > 0 ? group_rows : g_tile_group_rows > 0 ? g_tile_group_rows : (nbn <= 8 ? 6 : (nbn <= 16 ? 5 : 4));
+    hipLaunchKernelGGL((gemm_nt8_kernel<Epi, ABL>), dim3(nblk), dim3(512), lds, st, A, lda, W, ldw, M, N, K, gm, epi);
+    return hipGetLastError() == hipSuccess;
 }
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
@@ -591,14 +771,15 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
     return hipGetLastError() == hipSuccess;
 }
 
-// Tile choice: 256x256 (8 waves, 2 stages, LDS-DMA issue spread over the MFMA groups) when N allows it
-// and the grid fills the chip, then
+// Tile choice: 256x256 (the 8-phase kernel; for K = 64 the 2-stage kernel with the LDS-DMA issue spread over the MFMA
+// groups) when N allows it and the grid fills the chip, then
 // 256x128 (8 waves, 3 stages, one workgroup per CU) when that grid still fills the chip,
 // 64x64 (4 waves, 4 stages) for the skinny decoder-side problems. Activation buffers are allocated with
 // their row count rounded up to 256, so the row tiles may over-read.
 template <class Epi>
 static bool dispatch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st) {
     const long big = (long)((M + 255) / 256) * (N / 128);
+    if (N % 256 == 0 && big >= 192 && K >= 2 * BK) return launch8<Epi>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 256 == 0 && big >= 192) return launch<256, 256, 2, 4, 2, Epi, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 128 == 0 && M >= 192 && big >= 128) return launch<256, 128, 4, 2, 3, Epi>(A, lda, W, ldw, M, N, K, epi, st);
     return launch<64, 64, 2, 2, 4, Epi>(A, lda, W, ldw, M, N, K, epi, st);
@@ -610,6 +791,12 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
     switch (variant) {
         case 0: return launch<256, 128, 4, 2, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 1: return launch<256, 256, 2, 4, 2, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 50: return launch8<EpiF16>(A, lda, W, ldw, M, N, K, e, st);                                       // 8-phase kernel, plain f16 epilogue
+        case 53: return launch8<EpiF16, kStamps>(A, lda, W, ldw, M, N, K, e, st);                              // ... with per-section cycle stamps
+        case 54: return launch8<EpiF16, kNoStagger>(A, lda, W, ldw, M, N, K, e, st);                           // ... all eight waves in step
+        case 55: return launch8<EpiF16, kIssueFirst>(A, lda, W, ldw, M, N, K, e, st);                          // ... LDS-DMA issued before the fragment reads
+        case 51: return launch8<EpiResidual>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);
+        case 52: return launch8<EpiF16>(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, (const float *)W, 1, 1.0f}, st);   // bias + GELU
         case 2: return launch<128, 128, 2, 2, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 3: return launch<128, 128, 2, 2, 2, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 4: return launch<256, 128, 4, 2, 2, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
@@ -775,7 +962,7 @@ bool gemm_enc_qk(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp
 bool gemm_enc_vt(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Vt, const float *bias, hipStream_t st) {
     if (!gemm_enc_qkv_is_split(M, d, T)) return false;
     const int Mp = (M + 255) / 256 * 256;
-    return launch<256, 256, 2, 4, 2, EpiVt, kSpread | kFirstHalf>(W + (long)2 * d * d, d, xn, d, d, Mp, d, EpiVt{Vt, bias + 2 * d, H, T, Tp, M}, st, 1, d / 256);
+    return launch8<EpiVt>(W + (long)2 * d * d, d, xn, d, d, Mp, d, EpiVt{Vt, bias + 2 * d, H, T, Tp, M}, st, d / 256);
 }
 bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *Kb, f16 *Vt, const float *bias, hipStream_t st) {
     return dispatch(xn, d, W, d, M, 3 * d, d, EpiEncQKV{Q, Kb, Vt, bias, d, H, T, Tp}, st);

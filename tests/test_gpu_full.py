@@ -452,7 +452,9 @@ def test_quantised_files_load_and_match(wr, oracle, model_path):
         ctx = wr.WhisperContext(path); st = ctx.create_state()
         ost.pcm_to_mel(pcm); st.pcm_to_mel(pcm)
         ref = ost.encode(0); st.encode(0)
-        assert np.abs(st.encoder_output() - ref).max() <= 3e-2, ftype
+        qerr = float(np.abs(st.encoder_output() - ref).max())
+        print("ftype", ftype, "encoder max abs err", qerr)
+        assert qerr <= 5e-3, (ftype, qerr)          # observed 1.3e-3 - 2.5e-3; twice that
         st.free(); ctx.free(); ost.close(); om.close()
 
 

@@ -45,19 +45,21 @@ def test_turbo_one_utterance_matches_oracle(wr, oracle, turbo_path):
     err = float(np.abs(got - ref).max())
     print("turbo encoder: max abs err", err, "max |ref|", scale, "ref std", float(ref.std()))
     # fp16 GEMM operands and activations through 32 layers against the oracle's fp32 activations (fp16-rounded weights in both)
-    assert err <= 2e-2 * max(1.0, scale), (err, scale)
+    assert err <= 4e-3, (err, scale)                                               # observed 1.9e-3 at max |ref| 4.6; twice that
+    kv_err = 0.0
     for layer in range(om.n_text_layer):
         k_ref, v_ref = ost.cross_kv(layer)
         k, v = st.cross_kv(layer)
-        assert np.abs(k - k_ref).max() <= 2e-2 * max(1.0, float(np.abs(k_ref).max()))
-        assert np.abs(v - v_ref).max() <= 2e-2 * max(1.0, float(np.abs(v_ref).max()))
+        kv_err = max(kv_err, float(np.abs(k - k_ref).max()), float(np.abs(v - v_ref).max()))
+    print("turbo cross K/V: max abs err", kv_err)
+    assert kv_err <= 8e-3, kv_err                                                  # observed 3.9e-3 (one fp16 step at these magnitudes); twice that
     sot = om.special("sot")
     toks = [sot, sot + 1, om.special("transcribe"), om.special("not"), 1000, 2000, 3000, 4000]
     lref = ost.decode(toks, 0, 0, logits_all=True)
     lgot = st.decode_logits_all(toks, 0)
     lerr = float(np.abs(lgot - lref).max())
     print("turbo logits: max abs err", lerr, "ref std", float(lref.std()))
-    assert lerr <= 2e-2 * max(1.0, float(np.abs(lref).max())), lerr
+    assert lerr <= 2e-2, lerr                                                      # observed 9.1e-3 at a logit spread of 4.3; twice that
     # the decisions a greedy decoder takes from these rows (margins of the synthetic model are far above the error)
     assert (lgot.argmax(1) == lref.argmax(1)).all()
     st.free(); ctx.free(); ost.close(); om.close()

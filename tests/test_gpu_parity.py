@@ -154,21 +154,24 @@ def test_encoder_decoder_parity(wr, oracle, golden, model_path, arch):
     got = st.encoder_output()
     err = np.abs(got - ref).max()
     print(arch, "encoder max abs err", err, "ref std", ref.std())
-    assert err <= 3e-2, err                                   # fp16 activations through the stack; values are O(1)
+    assert err <= 4e-3, err                                   # observed 1.4e-3 - 1.7e-3 (values are O(1)); twice that
     if f"{arch}_enc" in golden:
-        assert np.abs(got[::50] - golden[f"{arch}_enc"]).max() <= 5e-2
+        assert np.abs(got[::50] - golden[f"{arch}_enc"]).max() <= 8e-3       # transformers fp32 vs oracle 2.1e-3, plus the above
+    kv_err = 0.0
     for layer in range(om.n_text_layer):
         k_ref, v_ref = ost.cross_kv(layer)
         k, v = st.cross_kv(layer)
-        assert np.abs(k - k_ref).max() <= 3e-2 and np.abs(v - v_ref).max() <= 3e-2
+        kv_err = max(kv_err, float(np.abs(k - k_ref).max()), float(np.abs(v - v_ref).max()))
+    print(arch, "cross K/V max abs err", kv_err)
+    assert kv_err <= 8e-3, kv_err
     toks = [int(t) for t in golden[f"{arch}_tokens" if f"{arch}_tokens" in golden else "micro.en_tokens"]]
     lref = ost.decode(toks, 0, 0, logits_all=True)
     lgot = st.decode_logits_all(toks, 0)
     lerr = np.abs(lgot - lref).max()
     print(arch, "logits max abs err", lerr, "std", lref.std())
-    assert lerr <= 3e-2, lerr
+    assert lerr <= 6e-3, lerr                                 # observed 1.9e-3 - 3.1e-3; twice that
     if f"{arch}_logits_sub" in golden:
-        assert np.abs(lgot[:, ::97] - golden[f"{arch}_logits_sub"]).max() <= 5e-2
+        assert np.abs(lgot[:, ::97] - golden[f"{arch}_logits_sub"]).max() <= 1e-2
     # incremental decode through the paged cache equals the batched pass
     st.decode(toks[:4], 0)
     inc = np.stack([st.decode([toks[i]], i) for i in range(4, 8)])
