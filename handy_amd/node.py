@@ -45,3 +45,47 @@ def gather_token_records(rec: np.ndarray, rows_per_rank: int, device=None) -> Op
     allr = torch.cat(out).cpu().numpy()
     allr = allr[allr[:, 0] >= 0]
     return allr[np.argsort(allr[:, 0], kind="stable")]
+
+
+class BatchQueue:
+    """A shared queue of batch numbers 0 .. n_batches-1 for the ranks of one job: every rank pulls the next batch when it is
+    free, so ranks whose utterances decode for longer simply pull fewer (dynamic balance by utterance batch; no data moves
+    between GPUs). The counter is one atomic fetch-add on the job's rendezvous store (torch.distributed's TCP store), not a
+    collective; without a process group it is a local counter."""
+
+    def __init__(self, n_batches: int, name: str = "wmi_batch_queue"):
+        import torch.distributed as dist
+        self.n_batches, self.key, self._local = int(n_batches), name, 0
+        self.store = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed.distributed_c10d import _get_default_store
+            self.store = _get_default_store()
+
+    def pull(self) -> Optional[int]:
+        if self.store is not None:
+            i = int(self.store.add(self.key, 1)) - 1
+        else:
+            i, self._local = self._local, self._local + 1
+        return i if i < self.n_batches else None
+
+    def __iter__(self):
+        while True:
+            i = self.pull()
+            if i is None:
+                return
+            yield i
+
+
+def gather_ragged_records(rec: np.ndarray, device=None) -> Optional[np.ndarray]:
+    """gather_token_records for ranks that hold different numbers of records (what a pulled queue leaves): the counts are
+    exchanged first, every rank pads to the largest. Rank 0 gets all records sorted by utterance index."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec[np.argsort(rec[:, 0], kind="stable")]
+    n = torch.tensor([len(rec)], dtype=torch.int64)
+    if device is not None:
+        n = n.to(device)
+    counts = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
+    dist.all_gather(counts, n)
+    return gather_token_records(rec, rows_per_rank=max(1, max(int(c.item()) for c in counts)), device=device)

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-breakdown --batch ${WMI_PMC_BATCH:-128} --tokens ${WMI_PMC_TOKENS:-4}"
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-breakdown --strong-total 0 --batch ${WMI_PMC_BATCH:-128} --tokens ${WMI_PMC_TOKENS:-4}"
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_COEXEC_CYCLES --kernel-trace -d $OUT/p1 -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/p1.log 2>&1 || { tail -3 $OUT/p1.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_MISC SQ_WAIT_ANY --kernel-trace -d $OUT/p2 -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/p2.log 2>&1 || { tail -3 $OUT/p2.log; exit 1; }
 python3 - <<PY

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${1:-x}
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown ${@:2} > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown --strong-total 0 ${@:2} > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)[0]

@@ -118,6 +118,47 @@ dist.barrier(); dist.destroy_process_group()
 """
 
 
+_QUEUE_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+from handy_amd.node import BatchQueue, pack_token_records, gather_ragged_records
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+rank, n_batches, per = dist.get_rank(), 13, 3
+mine = []
+for b in BatchQueue(n_batches):
+    time.sleep(0.03 if rank == 0 else 0.002)          # an uneven pair: the fast rank ends up with more batches
+    mine.append(b)
+idx = [b * per + k for b in mine for k in range(per)]
+rec = pack_token_records(idx, [[u, u + 1] for u in idx], 4)
+out = gather_ragged_records(rec)
+cnt = [None, None]
+dist.all_gather_object(cnt, len(mine))
+if rank == 0:
+    assert out[:, 0].tolist() == list(range(n_batches * per)), out[:, 0]          # every batch exactly once, in utterance order
+    assert all(out[u, 2:4].tolist() == [u, u + 1] for u in range(n_batches * per))
+    assert sum(cnt) == n_batches and cnt[1] > cnt[0], cnt
+    print("QUEUE_OK", cnt)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_process_batch_queue_over_gloo(tmp_path):
+    """The bulk driver's N > 1 path: ranks pull utterance batches from the shared queue until it is empty, then one ragged
+    gather of the token records on rank 0 (world_size 2, gloo, CPU)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "qworker.py"
+    script.write_text(_QUEUE_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "QUEUE_OK" in outs[0]
+    from handy_amd.node import BatchQueue
+    assert list(BatchQueue(4)) == [0, 1, 2, 3]            # without a process group: a local counter
+
+
 def test_two_process_gather_over_gloo(tmp_path):
     """The N>1 path (shard by utterance, gather token records on rank 0) with world_size 2 on CPU."""
     import socket
