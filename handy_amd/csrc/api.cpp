@@ -459,6 +459,7 @@ int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_block
     WMI_CATCH(-1)
 }
 
+#ifdef WMI_HARNESS       // benchmark harness entry points (libwhisper_mi355_harness.so only)
 int wmi_debug_read_gemm_stamps(unsigned long long *out, int n) { return wmi::gemm_read_stamps(out, n) ? 0 : -1; }
 void wmi_debug_set_tile_group(int rows) { if (rows >= 1) wmi::g_tile_group_rows = rows; }
 
@@ -562,5 +563,7 @@ int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_varian
     return rc;
     WMI_CATCH(-1)
 }
+
+#endif  // WMI_HARNESS
 
 }  // extern "C"

@@ -76,6 +76,7 @@ bool layer_norm(const float *x, const float *w, const float *b, f16 *out16, floa
     return hipGetLastError() == hipSuccess;
 }
 
+#ifdef WMI_HARNESS
 // Benchmark-only variants of the LayerNorm kernel (fp16 output only): V bit 0 = nontemporal loads and stores, bit 1 = weights and
 // bias requested before the statistics, bit 2 = 8 rows per workgroup.
 template <int V>
@@ -194,6 +195,8 @@ bool layer_norm_variant(int variant, const float *x, const float *w, const float
 #undef WMI_LNV
     return hipGetLastError() == hipSuccess;
 }
+
+#endif  // WMI_HARNESS
 
 // ------------------------------------------------------------------------------------------ attention
 // Non-causal softmax(Q K^T) V over T keys, heads of 64. Q is pre-scaled by 1/8 (exact in fp16).
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     }
 }
 
+#ifdef WMI_HARNESS
 // Micro-benchmark (harness only): time of 16-byte LDS writes / reads (four per iteration, 8 workgroups per CU) under a lane ->
 // (row, slot) pattern; rows are 128 bytes.
 //   0 linear (lane l -> byte 16 l)            1 one column: row l, slot 0
@@ -405,6 +409,8 @@ bool lds_pattern_bench(int pattern, int do_read, int iters, float *ms_out) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ok && hipGetLastError() == hipSuccess;
 }
+
+#endif  // WMI_HARNESS
 
 bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st) {
     if (B <= 0) return true;

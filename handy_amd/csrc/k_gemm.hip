@@ -269,8 +269,14 @@ template <class Epi> struct reads_output<Epi, decltype((void)Epi::kReadsOutput)>
 // gets a contiguous run of logical ids, and logical ids walk the tile grid in groups of 4-6 tile rows x
 // all tile columns, column-major inside a group, so the ~32 tiles an XCD works on at one time form a
 // patch that shares a few activation panels and weight panels through that L2.
-__device__ unsigned long long g_gemm_stamps[2048 * 8 * 8];      // diagnostic builds of the harness only (see gemm_variant)
-int g_tile_group_rows = 0;     // tile rows per group; 0 = chosen from the tile-column count (harness knob otherwise)
+#ifdef WMI_HARNESS
+__device__ unsigned long long g_gemm_stamps[2048 * 8 * 8];      // cycle stamps of the stamped harness variants (see gemm_variant)
+int g_tile_group_rows = 0;     // harness knob: tile rows per L2 group; 0 = chosen from the tile-column count
+#else
+// the product library has no stamped kernels and no knob: the stamp branches below are compiled out (ABL is 0 everywhere)
+static __device__ unsigned long long g_gemm_stamps[8];
+static constexpr int g_tile_group_rows = 0;
+#endif
 
 __device__ __forceinline__ void tile_coords(int p, int nbm, int nbn, int GM, int &bm, int &bn) {
     const int nblk = nbm * nbn;
@@ -785,6 +791,7 @@ static bool dispatch(const f16 *A, long lda, const f16 *W, long ldw, int M, int 
     return launch<64, 64, 2, 2, 4, Epi>(A, lda, W, ldw, M, N, K, epi, st);
 }
 
+#ifdef WMI_HARNESS
 // Tile-shape A/B harness (benchmark only): same kernel, explicit variant.
 bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, hipStream_t st) {
     const EpiF16 e{out, ldc, nullptr, 0, 1.0f};
@@ -827,6 +834,8 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
     }
     return false;
 }
+
+#endif  // WMI_HARNESS
 
 // ------------------------------------------------------------------------------------------ skinny split-K GEMM
 // The decoder multiplies a few hundred activation rows with weights that are read once per pass: the job is to
@@ -930,9 +939,11 @@ bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, i
     return hipGetLastError() == hipSuccess;
 }
 
+#ifdef WMI_HARNESS
 bool gemm_read_stamps(unsigned long long *out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * n) == hipSuccess;
 }
+#endif
 
 bool gemm_f16(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st) {
     return dispatch(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, bias, gelu, scale}, st);

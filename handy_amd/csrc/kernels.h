@@ -23,9 +23,11 @@ int gemm_pick_splits(int N, int K);                       // 1 = use the fused-e
 size_t gemm_splitk_workspace_bytes(int rows, int N, int K);   // bytes of ws[splits][rows][N] for this weight shape (0: it does not split)
 bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, int splits, float *ws, size_t ws_bytes, hipStream_t st);
 
+#ifdef WMI_HARNESS        // benchmark harness build only (libwhisper_mi355_harness.so)
 extern int g_tile_group_rows;
 bool gemm_read_stamps(unsigned long long *out, int n);
 bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, hipStream_t st);
+#endif
 
 // ---- k_load.hip : load-time expansion of block-quantised tensors ------------------------------
 int quant_block_bytes(int ttype);                          // bytes per 32-weight block of a ggml block type, 0 if not one
@@ -71,8 +73,10 @@ bool mel_window_normalized(const float *mel, const WinDesc *wins, int n_win, int
 
 // ---- k_encoder.hip --------------------------------------------------------------------------
 // y = LayerNorm(x) * w + b (eps 1e-5); writes fp16 (out16) and/or fp32 (out32); rows gathered through `gather` if given
-bool lds_pattern_bench(int pattern, int do_read, int iters, float *ms_out);   // LDS access-pattern micro-benchmark (harness)
-bool layer_norm_variant(int variant, const float *x, const float *w, const float *b, f16 *out16, int M, int d, hipStream_t st);   // benchmark harness
+#ifdef WMI_HARNESS
+bool lds_pattern_bench(int pattern, int do_read, int iters, float *ms_out);   // LDS access-pattern micro-benchmark
+bool layer_norm_variant(int variant, const float *x, const float *w, const float *b, f16 *out16, int M, int d, hipStream_t st);   // LayerNorm A/B
+#endif
 bool layer_norm(const float *x, const float *w, const float *b, f16 *out16, float *out32, int M, int d, const int *gather, hipStream_t st);
 // non-causal attention over T keys (padded to Tp), heads of 64: Q,K [B][H][Tp][64], Vt [B][H][64][Tp] -> att [B*T][H*64]
 bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st);

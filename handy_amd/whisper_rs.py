@@ -25,6 +25,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwhisper_mi355.so")
+# the same sources built with -DWMI_HARNESS: GEMM / LayerNorm / LDS A/B kernels and their wmi_bench_* entry points (scripts/ only)
+HARNESS_LIB_PATH = os.path.join(_HERE, "libwhisper_mi355_harness.so")
 
 whisper_token = C.c_int32
 

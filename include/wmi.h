@@ -96,12 +96,16 @@ WHISPER_API int wmi_debug_gemm_gelu(int M, int N, int K, const float *A, const f
  * block) on host buffers: blocks -> out[n_blocks * 32] as fp16 bit patterns. */
 WHISPER_API int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_blocks, unsigned short *out);
 
+#ifdef WMI_HARNESS
+/* Benchmark harness (libwhisper_mi355_harness.so, built from the same sources with -DWMI_HARNESS; the product library does not
+ * carry these): tile-shape / schedule variants of the GEMM, cycle stamps, LayerNorm and LDS access-pattern A/B kernels. */
 WHISPER_API int wmi_debug_read_gemm_stamps(unsigned long long *out, int n);                             /* harness: per-section cycle sums of variant 14 */
 WHISPER_API void wmi_debug_set_tile_group(int rows);                                                    /* harness knob: tile rows per L2 group */
 WHISPER_API int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_variant, float *max_abs_diff); /* harness */
 WHISPER_API int wmi_bench_lds_pattern(int pattern, int do_read, int iters, float *ms_out);                /* 16-byte LDS access patterns, one workgroup per CU (harness) */
 WHISPER_API int wmi_bench_layer_norm(int M, int d, int variant, int iters, float *ms_out);            /* LayerNorm A/B harness (variant 100 = the shipped kernel) */
 WHISPER_API int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out);            /* tile-shape A/B harness, random fp16 operands */
+#endif
 
 /* Per-kernel-class device time, measured with HIP events on the engine's stream. */
 enum wmi_kernel_class { WMI_K_MEL = 0, WMI_K_ENC_GEMM, WMI_K_ENC_ATTN, WMI_K_ENC_OTHER, WMI_K_DEC_GEMM, WMI_K_DEC_CROSS_ATTN, WMI_K_DEC_OTHER, WMI_K_COUNT };

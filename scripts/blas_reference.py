@@ -4,7 +4,7 @@ import ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from handy_amd import whisper_rs as wr
-L = wr.load_library()
+L = wr.load_library(wr.HARNESS_LIB_PATH)      # the benchmark-harness build of the library
 L.wmi_bench_gemm.restype = C.c_int
 L.wmi_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
 dev = torch.device("cuda", 0)

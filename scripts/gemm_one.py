@@ -2,7 +2,7 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from handy_amd import whisper_rs as wr
-L = wr.load_library()
+L = wr.load_library(wr.HARNESS_LIB_PATH)      # the benchmark-harness build of the library
 L.wmi_bench_gemm.restype = C.c_int
 L.wmi_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
 v = int(sys.argv[1]); M, N, K = (int(x) for x in sys.argv[2:5])

@@ -2,7 +2,7 @@
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from handy_amd import whisper_rs as wr
-L = wr.load_library()
+L = wr.load_library(wr.HARNESS_LIB_PATH)      # the benchmark-harness build of the library
 L.wmi_bench_layer_norm.restype = C.c_int
 L.wmi_bench_layer_norm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 192000

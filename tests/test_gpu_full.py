@@ -311,9 +311,10 @@ def test_full_params_variants_match_oracle(wr, oracle, model_path, variant):
     del keep
 
 
-def test_batching_front_equals_one_call_at_a_time(wr, model_path):
+def test_batching_front_equals_one_call_at_a_time(wr, oracle, model_path):
     """handy_amd.manager.TranscriptionManager: concurrent transcribe() calls are served by shared GPU batches and
-    every caller still gets exactly what a lone call returns (beam search, transcribe-rs defaults)."""
+    every caller still gets exactly what a lone call returns (beam search, transcribe-rs defaults) -- which is the text the
+    oracle's whisper_full produces for that clip with the same parameters."""
     import threading
     from handy_amd.manager import TranscriptionManager
     path = model_path("micro", decisive=4.0)
@@ -322,6 +323,12 @@ def test_batching_front_equals_one_call_at_a_time(wr, model_path):
     lone.load_model(path)
     expect = [lone.transcribe(p) for p in pcms]
     lone.unload_model()
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    fp = wr.WhisperEngine()._full_params(wr.WhisperInferenceParams(language="en"))      # what the manager hands to the engine
+    op = _oracle_params(oracle, fp, beam_candidates_topk=1)
+    ref = [b"".join(s["text"] for s in ost.full(op, p)).decode("utf-8", errors="replace").strip() for p in pcms]
+    ost.close(); om.close()
+    assert expect == ref
     tm = TranscriptionManager(max_batch=8, collect_ms=50.0, selected_language="en")
     tm.load_model(path)
     got = [None] * len(pcms)
@@ -335,7 +342,7 @@ def test_batching_front_equals_one_call_at_a_time(wr, model_path):
 
 
 @pytest.mark.parametrize("arch,lang", [("micro.en", "en"), ("micro", "auto")])
-def test_window_memo_on_a_growing_recording(wr, model_path, arch, lang):
+def test_window_memo_on_a_growing_recording(wr, oracle, model_path, arch, lang):
     """Handy's live coaching transcribes the whole recording so far every few seconds (reference live_coaching.rs:84-97).
     With the window memo on, the interior 30 s windows of the earlier calls are taken over instead of being encoded and
     decoded again, and every call returns exactly what it returns with the memo off -- greedy with temperature fallback
@@ -360,6 +367,12 @@ def test_window_memo_on_a_growing_recording(wr, model_path, arch, lang):
             for x, y in zip(a, b):
                 assert (x.t0, x.t1, x.text, x.tokens) == (y.t0, y.t1, y.text, y.tokens), secs
             assert plain.batch_n_fallbacks(0) == memo.batch_n_fallbacks(0)
+            if secs >= 77:          # ... and it is what the oracle's whisper_full returns for that recording (the draws at T > 0 included)
+                om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+                ref = ost.full(_oracle_params(oracle, fp, lang=None, beam_candidates_topk=1), pcm)
+                assert _same(b, ref), (secs, [x.tokens[:6] for x in b[:3]], [r["tokens"][:6] for r in ref[:3]])
+                assert memo.batch_n_fallbacks(0) == ost.n_fallbacks
+                ost.close(); om.close()
         stats = memo.window_cache_stats()
         assert stats["stores"] >= 2 and stats["hits"] >= (4 if lang == "en" else 2), stats       # windows 0 and 1 are interior from the second peek on
         assert plain.window_cache_stats() == {"hits": 0, "stores": 0}
