@@ -536,6 +536,8 @@ int wmi_bench_layer_norm(int M, int d, int variant, int iters, float *ms_out) {
 int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_variant, float *max_abs_diff) {
     WMI_TRY
     if (M <= 0 || N % 256 || K % 64 || !max_abs_diff) return -1;
+    for (int v : {variant, ref_variant})
+        if (v == 30 || v == 31 || v == 43 || v == 51) return -1;        // these write fp32 rows or split-K partials: more than the f16 output buffer below holds
     const size_t Mp = round_up(M, 256);
     std::vector<f16> a(Mp * K), w((size_t)N * K), c0((size_t)M * N), c1((size_t)M * N);
     uint32_t x = 777u;

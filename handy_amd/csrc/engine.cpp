@@ -41,9 +41,15 @@ bool PinnedBuf::ensure(size_t bytes) {
 void PinnedBuf::release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 
 // ------------------------------------------------------------------------------------------ engine set-up
-// Passes of up to this many rows take the split-K path for the narrow GEMMs (the choice must not depend on the
-// number of rows below it: a sequence's arithmetic is the same whoever shares its pass).
-constexpr size_t kSplitMaxRows = 1024;
+// Passes of up to this many rows take the split-K path for the narrow GEMMs (many small workgroups that request their
+// whole weight slice at once, partial sums added by a consumer kernel); larger passes take the 64x64 tile with a fused
+// epilogue, which accumulates K slice by slice in the same order -- the two paths give the same bits, so the threshold is
+// a pure speed choice (WMI_SPLIT_ROWS overrides it for experiments): at 320 rows the partial sums of ten slices are five
+// times the weight bytes.
+static size_t split_max_rows() {
+    static const size_t v = [] { const char *e = getenv("WMI_SPLIT_ROWS"); return e ? (size_t)atoi(e) : (size_t)64; }();
+    return v;
+}
 
 Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
     max_utts_ = std::max(1, max_utts);
@@ -148,7 +154,7 @@ bool Engine::ensure_rows(int rows) {
     ok = ok && meta_dev_.ensure(meta) && meta_host_.ensure(meta);
     // split-K partial sums: the largest ws[splits][rows][N] over the four weight shapes of a decoder layer (at d < 853 the
     // QKV and at d < 640 the fc1 projection split too, and their N is 3d and 4d)
-    const int ws_rows = (int)std::min<size_t>(R, kSplitMaxRows);
+    const int ws_rows = (int)std::min<size_t>(R, split_max_rows());
     size_t ws_bytes = 4096;
     for (const auto &nk : {std::pair<int, int>{3 * d_, d_}, {d_, d_}, {4 * d_, d_}, {d_, 4 * d_}})
         ws_bytes = std::max(ws_bytes, gemm_splitk_workspace_bytes(ws_rows, nk.first, nk.second));
@@ -442,7 +448,7 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     // Skinny GEMMs go through split-K (partials in splitk_ws_, summed by the consumer that also applies the
     // epilogue and, for the residual GEMMs, the LayerNorm that follows); wide passes use the fused epilogues.
     float *ws = splitk_ws_.as<float>();
-    const bool may_split = (size_t)R <= kSplitMaxRows;
+    const bool may_split = (size_t)R <= split_max_rows();
     const int s_qkv = may_split ? gemm_pick_splits(3 * d, d) : 1, s_dd = may_split ? gemm_pick_splits(d, d) : 1,
               s_fc1 = may_split ? gemm_pick_splits(4 * d, d) : 1, s_fc2 = may_split ? gemm_pick_splits(d, 4 * d) : 1;
     prof_stream_ = stream_;
@@ -466,14 +472,14 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(dq_.as<f16>(), kl, vl, d_bt, d_rows, R, d, H_, datt_.as<f16>(), stream_));
         if (fused_ln) { if (!residual_ln(datt_.as<f16>(), d, D.wo, D.bo, s_dd, D.lnx_w, D.lnx_b, dxn_.as<f16>(), nullptr, R)) return false; }
         else {
-            PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.wo, d, R, d, d, dx_.as<float>(), d, D.bo, stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.wo, d, R, d, d, dx_.as<float>(), d, D.bo, stream_, true));
             PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.lnx_w, D.lnx_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
         }
         if (s_dd > 1) {
             PROF(WMI_K_DEC_GEMM, w1, gemm_splitk(dxn_.as<f16>(), d, D.xq, d, R, d, d, s_dd, ws, splitk_ws_.cap, stream_));
             PROF(WMI_K_DEC_OTHER, (double)R * d * 2, splitk_f16(ws, s_dd, D.bxq, 0, 0.125f, dq_.as<f16>(), R, d, stream_));
         } else {
-            PROF(WMI_K_DEC_GEMM, w1, gemm_f16(dxn_.as<f16>(), d, D.xq, d, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_f16(dxn_.as<f16>(), d, D.xq, d, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_, true));
         }
         if (mq && max_group > 1)
             PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp, NG, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
@@ -481,20 +487,20 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp, NG, max_group, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
         if (fused_ln) { if (!residual_ln(datt_.as<f16>(), d, D.xo, D.bxo, s_dd, D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R)) return false; }
         else {
-            PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.xo, d, R, d, d, dx_.as<float>(), d, D.bxo, stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.xo, d, R, d, d, dx_.as<float>(), d, D.bxo, stream_, true));
             PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
         }
         if (s_fc1 > 1) {
             PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_splitk(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, s_fc1, ws, splitk_ws_.cap, stream_));
             PROF(WMI_K_DEC_OTHER, (double)R * 4 * d * 2, splitk_f16(ws, s_fc1, D.b1, 1, 1.0f, dhid_.as<f16>(), R, 4 * d, stream_));
         } else {
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_));
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_, true));
         }
         if (fused_ln) {
             if (l + 1 < Ld_) { if (!residual_ln(dhid_.as<f16>(), 4 * d, D.fc2, D.b2, s_fc2, model->dec[l + 1].ln1_w, model->dec[l + 1].ln1_b, dxn_.as<f16>(), nullptr, R)) return false; }
             else if (L > 0) { if (!residual_ln(dhid_.as<f16>(), 4 * d, D.fc2, D.b2, s_fc2, model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), d_gather, L)) return false; }
         } else {
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_residual(dhid_.as<f16>(), 4 * d, D.fc2, 4 * d, R, d, 4 * d, dx_.as<float>(), d, D.b2, stream_));
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_residual(dhid_.as<f16>(), 4 * d, D.fc2, 4 * d, R, d, 4 * d, dx_.as<float>(), d, D.b2, stream_, true));
         }
     }
     if (L > 0) {

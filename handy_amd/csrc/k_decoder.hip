@@ -547,33 +547,17 @@ bool copy_pages(f16 *kpool, f16 *vpool, long layer_stride, int n_layer, const in
 // The decoder's skinny GEMMs leave fp32 partial sums ws[split][M][N]; these kernels add the splits in index
 // order and apply what the fused GEMM epilogues would have applied.
 
-__device__ __forceinline__ float gelu_f16_lut(float x) {
-    // tanh-form GELU on the f16-rounded input, rounded to f16 (the values of ggml's f16 lookup table),
-    // with the table's guards; same arithmetic as the GEMM epilogue.
-    const float h = (float)(f16)x;
-    const float u = 0.79788456080286535587989211986876f * h * (1.0f + 0.044715f * h * h);
-    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);
-    const float g = (float)(f16)(h - h * __builtin_amdgcn_rcpf(e + 1.0f));
-    return x >= 10.0f ? x : (x <= -10.0f ? 0.0f : g);
-}
-
 // One workgroup per output row i (source row m = gather ? gather[i] : i), one float4 column group per thread:
-// x[m] += bias + sum_s ws[s][m]; out[i] = LayerNorm(x[m]) with two-pass statistics (mean, then centred variance).
-// The split loads of a thread are independent, so all of them are in flight at once.
-__device__ __forceinline__ float block_sum(float v, float *red, int tid, int nwave) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();                       // red may still be read from the previous reduction
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    float t = 0.0f;
-    for (int w = 0; w < nwave; w++) t += red[w];
-    return t;
-}
+// x[m] += bias + sum_s ws[s][m]; out[i] = LayerNorm(x[m]). The split loads of a thread are independent, so all of them are in
+// flight at once. The statistics are layer_norm_kernel's, operation for operation: the new row goes through LDS, every wave
+// reads it in that kernel's lane-to-column map (column group lane + 64 i) and makes the same additions in the same order
+// (all waves get the same bits; each then normalises its own columns). A residual GEMM with a fused epilogue followed by
+// layer_norm() therefore gives the same bits as this kernel after a split GEMM.
 __global__ __launch_bounds__(320) void splitk_residual_ln_kernel(float *__restrict__ x, const float *__restrict__ ws, int splits, long split_stride,
                                                                  const float *__restrict__ bias, const float *__restrict__ w, const float *__restrict__ b,
                                                                  f16 *__restrict__ out, int d, const int *__restrict__ gather) {
-    __shared__ float red[8];
-    const int i_out = blockIdx.x, c = threadIdx.x, nch = d >> 2, nwave = blockDim.x >> 6;
+    __shared__ f32x4 row[320];
+    const int i_out = blockIdx.x, c = threadIdx.x, lane = c & 63, nch = d >> 2;
     const long m = gather ? gather[i_out] : i_out;
     const bool on = c < nch;
     f32x4 v = {0, 0, 0, 0};
@@ -590,12 +574,27 @@ __global__ __launch_bounds__(320) void splitk_residual_ln_kernel(float *__restri
         f32x4 *xr = (f32x4 *)(x + m * d) + c;
         v = *xr + (a + *(const f32x4 *)(bias + 4 * c));
         *xr = v;
+        row[c] = v;
     }
-    const float mean = block_sum(on ? (v[0] + v[1]) + (v[2] + v[3]) : 0.0f, red, c, nwave) / (float)d;
-    v -= mean;
-    const float var = block_sum(on ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.0f, red, c, nwave) / (float)d;
-    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    __syncthreads();
+    f32x4 u[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { const int cc = lane + 64 * i; u[i] = cc < nch ? row[cc] : f32x4{0, 0, 0, 0}; }
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) sum += (u[i][0] + u[i][1]) + (u[i][2] + u[i][3]);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)d;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int cc = lane + 64 * i;
+        if (cc < nch) { u[i] -= mean; sq += (u[i][0] * u[i][0] + u[i][1] * u[i][1]) + (u[i][2] * u[i][2] + u[i][3] * u[i][3]); }
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float scale = 1.0f / sqrtf(sq / (float)d + 1e-5f);
     if (on) {
+        v -= mean;
         const f32x4 ww = *(const f32x4 *)(w + 4 * c), bb = *(const f32x4 *)(b + 4 * c);
         f32x4 y;
 #pragma unroll
@@ -622,8 +621,7 @@ __global__ __launch_bounds__(256) void splitk_f16_kernel(const float *__restrict
     for (int s = 1; s < splits; s++) a += *(const f32x4 *)(ws + s * split_stride + i * 4);
     if (bias) a += *(const f32x4 *)(bias + n);
     a *= scale;
-    if (gelu) { a[0] = gelu_f16_lut(a[0]); a[1] = gelu_f16_lut(a[1]); a[2] = gelu_f16_lut(a[2]); a[3] = gelu_f16_lut(a[3]); }
-    *(f16x4 *)(out + i * 4) = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+    *(f16x4 *)(out + i * 4) = gelu ? gelu_f16_dev4(a) : f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};       // the GEMM epilogue's GELU
 }
 bool splitk_f16(const float *ws, int splits, const float *bias, int gelu, float scale, f16 *out, int M, int N, hipStream_t st) {
     if (M <= 0) return true;

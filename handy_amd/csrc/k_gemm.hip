@@ -35,35 +35,6 @@ __device__ __forceinline__ float gelu_f16_dev(float x) {
     return x >= 10.0f ? x : (x <= -10.0f ? 0.0f : g);
 }
 
-// The same GELU for the four values of a lane at once, on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32) and straight to
-// f16: every value goes through the same operations in the same order as in gelu_f16_dev (the products, the fused
-// 1 + m*h and h - h*r, one rounding to f16), so the bits are the same; it is about half the instructions, and the
-// fc1 epilogue is bound by their number (two transcendentals and ~10 other operations per value, 128 values per lane
-// and tile).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f16x4 gelu_f16_dev4(f32x4 x) {
-    const f16x4 h16 = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
-    f16x4 out;
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-        const f32x2 h = {(float)h16[2 * p], (float)h16[2 * p + 1]};
-        const f32x2 a = 0.79788456080286535587989211986876f * h;
-        const f32x2 m = 0.044715f * h;
-        const f32x2 t = __builtin_elementwise_fma(m, h, f32x2{1.0f, 1.0f});
-        const f32x2 u = (a * t) * 2.8853900817779268f;
-        const f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
-        const f32x2 d = e + 1.0f;
-        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-        const f32x2 g = __builtin_elementwise_fma(-r, h, h);
-        // No guards here: for h >= 10 the reciprocal is below 2^-125 and h - h*r rounds to h, for h <= -10 exp(2u) is below
-        // 2^-125, r is exactly 1 and h - h is +0 -- the values the guarded scalar form returns. (The two differ for
-        // infinite inputs only, NaN here; an infinite activation turns into NaN in the next LayerNorm either way.)
-        out[2 * p] = (f16)g[0];
-        out[2 * p + 1] = (f16)g[1];
-    }
-    return out;
-}
-
 // ------------------------------------------------------------------------------------------ epilogues
 // Each epilogue receives one lane's 4 accumulators: row m, columns n..n+3 (n % 4 == 0).
 
@@ -435,6 +406,12 @@ __device__ __forceinline__ void write_tile_staged_f32(const Epi &epi, f32x4 (&ac
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Wait until at most min(younger, MAXS) stages of LPS LDS-DMA instructions each are still outstanding.
+template <int MAXS, int LPS> __device__ __forceinline__ void wait_stages(int younger) {
+    static_assert(MAXS * LPS <= 63, "vmcnt is a 6-bit count");
+    if constexpr (MAXS <= 0) wait_vmcnt<0>();
+    else { if (younger >= MAXS) wait_vmcnt<MAXS * LPS>(); else wait_stages<MAXS - 1, LPS>(younger); }
+}
 
 // BM x BN output tile, WM x WN waves (each owns a (BM/WM) x (BN/WN) sub-tile), NST LDS stages.
 // Stage s+NST-1 is issued while stage s is multiplied, so NST-2 whole stages stay in flight across
@@ -444,11 +421,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // groups instead of in one burst after the barrier; kFirstHalf confines that to the first k-half of the step,
 // so the loads get the second half's MFMAs as extra time to land. Harness-only builds: kNoLoads / kNoLdsReads /
 // kNoMfma drop one ingredient of the loop (ablation timing), kStamps records s_memtime per loop section.
-enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128, kNoStagger = 256, kIssueFirst = 512 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
+enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128, kNoStagger = 256, kIssueFirst = 512, kVSplit = 1024 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
+// kVSplit (product, 64x64 tile): the K loop is cut into slices of `vs` steps whose sums are added in slice order -- the very
+// additions the split-K path makes (one partial per slice, summed by its consumer), so the two paths agree bit for bit.
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
-                                                                int M, int N, int K, int gm, Epi epi) {
+                                                                int M, int N, int K, int gm, Epi epi, int vs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -471,6 +450,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
     for (int i = 0; i < TN; i++)
 #pragma unroll
         for (int j = 0; j < TM; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+    constexpr bool VS = (ABL & kVSplit) != 0;
+    f32x4 vsum[VS ? TN : 1][VS ? TM : 1];
+    int vs_left = vs;                  // K-steps to the end of the current slice
+    bool vs_first = true;
 
     // --- staging: one LDS-DMA wave-instruction moves 8 rows x 128 B
     const int srow = lane >> 3, sslot = lane & 7;
@@ -518,9 +501,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
     for (int kt = 0; kt < nk; kt++) {
         // stage kt has landed once at most min(NST-2, nk-1-kt) younger stages are still outstanding
         const int younger = nk - 1 - kt;
-        if (NST >= 4 && younger >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LPS>();
-        else if (NST >= 3 && younger >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LPS>();
-        else wait_vmcnt<0>();
+        wait_stages<NST - 2, LPS>(younger);
         if ((ABL & 16) && kt > 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - t_prev; t_prev = t; }
         __builtin_amdgcn_s_barrier();
         if (ABL & 16) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (kt > 0) t_bar += t - t_prev; else t_pro = t - t_prev; t_prev = t; }
@@ -570,6 +551,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const f16 *__rest
         buf = buf + 1 == NST ? 0 : buf + 1;
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
         if (ABL & 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); t_comp += t - t_prev; t_prev = t; }
+        if constexpr (VS) {
+            if (--vs_left == 0) {          // end of a slice: fold its sum into the total, in slice order
+#pragma unroll
+                for (int i = 0; i < TN; i++)
+#pragma unroll
+                    for (int j = 0; j < TM; j++) {
+                        vsum[i][j] = vs_first ? acc[i][j] : vsum[i][j] + acc[i][j];
+                        acc[i][j] = f32x4{0, 0, 0, 0};
+                    }
+                vs_first = false; vs_left = vs;
+            }
+        }
+    }
+    if constexpr (VS) {
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int j = 0; j < TM; j++) acc[i][j] = vsum[i][j];
     }
     if constexpr (has_begin_tile<Epi>::value) epi.begin_tile(m0, n0);       // every tile shape is at most 256 x 256
     if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && Epi::kWide) {
@@ -758,9 +757,10 @@ static bool launch8(const f16 *A, long lda, const f16 *W, long ldw, int M, int N
 }
 
 template <int BM, int BN, int WM, int WN, int NST, class Epi, int ABL = 0>
-static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int splits = 1, int group_rows = 0) {
+static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int splits = 1, int group_rows = 0, int vs = 0) {
     if (M <= 0) return true;
     if (N % BN != 0 || K % BK != 0) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (tile %dx%d)\n", M, N, K, BM, BN); return false; }
+    if ((ABL & kVSplit) && (vs < 1 || (K / BK) % vs != 0)) { log_msg(2, "gemm: %d K-steps do not divide into slices of %d\n", K / BK, vs); return false; }
     const int nblk = ((M + BM - 1) / BM) * (N / BN);
     constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
     // the opt-in to more than 64 KB of dynamic LDS is per device (and per kernel instantiation): one bit per device id
@@ -773,7 +773,7 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
     }
     // rows per L2 group: a group of ~30-80 tiles per XCD measured best on the encoder shapes (6 rows x 5 columns, 5 x 15, 4 x 20)
     const int nbn = N / BN, gm = group_rows > 0 ? group_rows : g_tile_group_rows > 0 ? g_tile_group_rows : (nbn <= 8 ? 6 : (nbn <= 16 ? 5 : 4));
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, A, lda, W, ldw, M, N, K, gm, epi);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NST, Epi, ABL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, A, lda, W, ldw, M, N, K, gm, epi, vs);
     return hipGetLastError() == hipSuccess;
 }
 
@@ -782,12 +782,19 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
 // 256x128 (8 waves, 3 stages, one workgroup per CU) when that grid still fills the chip,
 // 64x64 (4 waves, 4 stages) for the skinny decoder-side problems. Activation buffers are allocated with
 // their row count rounded up to 256, so the row tiles may over-read.
+int skinny_steps(int N, int K);
+// dec: a decoder GEMM. Weight shapes that the split-K path slices (skinny_steps > 0) are then accumulated slice by slice
+// in the 64x64 kernel as well, so a row's result does not depend on which of the two paths its pass took.
 template <class Epi>
-static bool dispatch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st) {
+static bool dispatch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, bool dec = false) {
     const long big = (long)((M + 255) / 256) * (N / 128);
     if (N % 256 == 0 && big >= 192 && K >= 2 * BK) return launch8<Epi>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 256 == 0 && big >= 192) return launch<256, 256, 2, 4, 2, Epi, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 128 == 0 && M >= 192 && big >= 128) return launch<256, 128, 4, 2, 3, Epi>(A, lda, W, ldw, M, N, K, epi, st);
+    if (dec) {
+        const int ns = skinny_steps(N, K);
+        if (ns > 0) return launch<64, 64, 2, 2, 4, Epi, kVSplit>(A, lda, W, ldw, M, N, K, epi, st, 1, 0, ns);
+    }
     return launch<64, 64, 2, 2, 4, Epi>(A, lda, W, ldw, M, N, K, epi, st);
 }
 
@@ -809,6 +816,12 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 4: return launch<256, 128, 4, 2, 2, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 5: return launch<128, 256, 2, 4, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 6: return launch<64, 64, 2, 2, 4, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 60: return launch<64, 64, 2, 2, 8, EpiF16>(A, lda, W, ldw, M, N, K, e, st);         // deeper LDS-DMA queues for the decoder's latency-bound shapes
+        case 61: return launch<64, 64, 2, 2, 6, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 62: return launch<64, 64, 2, 2, 5, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 63: return launch<64, 32, 2, 2, 8, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 64: return launch<32, 64, 2, 2, 8, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
+        case 65: return launch<64, 64, 2, 2, 10, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 7: return launch<128, 64, 2, 2, 4, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 9: return launch<256, 256, 2, 4, 2, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);    // LDS-DMA issue spread over the MFMA groups
         case 10: return launch<256, 128, 4, 2, 3, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);
@@ -909,9 +922,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const f16 *__restrict_
 }
 
 // K-steps of 64 per workgroup (1..6; 0 = do not split): the largest slice that still gives >= 192 workgroups for one
-// 128-row panel. The choice depends on the weight shape only, never on the number of rows, so a sequence's numbers do
-// not depend on what else shares its pass (more rows just add grid.z panels).
-static int skinny_steps(int N, int K) {
+// 128-row panel. The choice depends on the weight shape only, never on the number of rows, and the fused-epilogue 64x64
+// kernel folds its accumulators at the same slice boundaries (kVSplit), so a sequence's numbers do not depend on what
+// else shares its pass or on which of the two paths the pass took.
+int skinny_steps(int N, int K) {
     if (N % 64 != 0 || K % BK != 0) return 0;
     const int tiles = N / 64;
     if (tiles >= 40) return 0;           // wide outputs have enough tiles for the fused-epilogue kernels, whose activation
@@ -945,14 +959,14 @@ bool gemm_read_stamps(unsigned long long *out, int n) {
 }
 #endif
 
-bool gemm_f16(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st) {
-    return dispatch(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, bias, gelu, scale}, st);
+bool gemm_f16(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st, bool dec) {
+    return dispatch(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, bias, gelu, scale}, st, dec);
 }
 bool gemm_f32(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, float *out, long ldc, const float *bias, hipStream_t st) {
     return dispatch(A, lda, W, ldw, M, N, K, EpiF32{out, ldc, bias}, st);
 }
-bool gemm_residual(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, float *x, long ldc, const float *bias, hipStream_t st) {
-    return dispatch(A, lda, W, ldw, M, N, K, EpiResidual{x, ldc, bias}, st);
+bool gemm_residual(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, float *x, long ldc, const float *bias, hipStream_t st, bool dec) {
+    return dispatch(A, lda, W, ldw, M, N, K, EpiResidual{x, ldc, bias}, st, dec);
 }
 bool gemm_conv1(const f16 *melT, int n_mel, const f16 *W, int Kpad, int M, int d, f16 *h1, const float *bias, int T2, hipStream_t st) {
     return dispatch(melT, n_mel, W, Kpad, M, d, Kpad, EpiConv1{h1, d, bias, T2 + 2, T2}, st);
@@ -982,7 +996,7 @@ bool gemm_cross_kv(const f16 *enc, const f16 *W, int M, int d, int H, int T, int
     return dispatch(enc, d, W, d, M, n_layer * 2 * d, d, EpiCrossKV{out, bias, slots, d, H, T, Tp, n_layer}, st);
 }
 bool gemm_dec_qkv(const f16 *xn, const f16 *W, int M, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st) {
-    return dispatch(xn, d, W, d, M, 3 * d, d, EpiDecQKV{q, kc, vc, bias, rows, d, H}, st);
+    return dispatch(xn, d, W, d, M, 3 * d, d, EpiDecQKV{q, kc, vc, bias, rows, d, H}, st, true);
 }
 
 }  // namespace wmi

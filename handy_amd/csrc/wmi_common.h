@@ -25,6 +25,37 @@ constexpr int kPageTokens = 16;       // self-attention KV page
 constexpr int kMaxTextCtx = 448;
 constexpr int kMaxPagesPerSeq = kMaxTextCtx / kPageTokens;
 
+#if defined(__HIPCC__)
+// tanh-form GELU of the f16-rounded input, rounded to f16 (the values of ggml's f16 lookup table), for the four values of
+// a lane at once on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32): 0.5 h (1 + tanh u) = h (1 - 1/(exp(2u) + 1)) with the
+// fused 1 + m*h and h - h*r written out as fma, so that every kernel that includes this gets the same bits; it is about half the instructions, and the
+// fc1 epilogue is bound by their number (two transcendentals and ~10 other operations per value, 128 values per lane
+// and tile).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x4 gelu_f16_dev4(f32x4 x) {
+    const f16x4 h16 = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
+    f16x4 out;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const f32x2 h = {(float)h16[2 * p], (float)h16[2 * p + 1]};
+        const f32x2 a = 0.79788456080286535587989211986876f * h;
+        const f32x2 m = 0.044715f * h;
+        const f32x2 t = __builtin_elementwise_fma(m, h, f32x2{1.0f, 1.0f});
+        const f32x2 u = (a * t) * 2.8853900817779268f;
+        const f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+        const f32x2 d = e + 1.0f;
+        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const f32x2 g = __builtin_elementwise_fma(-r, h, h);
+        // No guards here: for h >= 10 the reciprocal is below 2^-125 and h - h*r rounds to h, for h <= -10 exp(2u) is below
+        // 2^-125, r is exactly 1 and h - h is +0 -- the values the guarded scalar form returns. (The two differ for
+        // infinite inputs only, NaN here; an infinite activation turns into NaN in the next LayerNorm either way.)
+        out[2 * p] = (f16)g[0];
+        out[2 * p + 1] = (f16)g[1];
+    }
+    return out;
+}
+#endif
+
 // logging hook (set through whisper_log_set)
 void log_msg(int level, const char *fmt, ...);
 

@@ -367,12 +367,6 @@ def test_window_memo_on_a_growing_recording(wr, oracle, model_path, arch, lang):
             for x, y in zip(a, b):
                 assert (x.t0, x.t1, x.text, x.tokens) == (y.t0, y.t1, y.text, y.tokens), secs
             assert plain.batch_n_fallbacks(0) == memo.batch_n_fallbacks(0)
-            if secs >= 77:          # ... and it is what the oracle's whisper_full returns for that recording (the draws at T > 0 included)
-                om = oracle.OracleModel(path); ost = oracle.OracleState(om)
-                ref = ost.full(_oracle_params(oracle, fp, lang=None, beam_candidates_topk=1), pcm)
-                assert _same(b, ref), (secs, [x.tokens[:6] for x in b[:3]], [r["tokens"][:6] for r in ref[:3]])
-                assert memo.batch_n_fallbacks(0) == ost.n_fallbacks
-                ost.close(); om.close()
         stats = memo.window_cache_stats()
         assert stats["stores"] >= 2 and stats["hits"] >= (4 if lang == "en" else 2), stats       # windows 0 and 1 are interior from the second peek on
         assert plain.window_cache_stats() == {"hits": 0, "stores": 0}
@@ -386,6 +380,25 @@ def test_window_memo_on_a_growing_recording(wr, oracle, model_path, arch, lang):
         assert memo.window_cache_stats()["hits"] == h0
         plain.free(); memo.free()
     ctx.free()
+    # ... and what the memo returns is what the oracle's whisper_full returns for the recording: greedy without draws on the
+    # weights with decisive margins (at temperature > 0 a draw turns on differences in the probabilities far below the
+    # parity tolerance, so the comparison above is between the engine's own two paths)
+    path4 = model_path(arch, decisive=4.0)
+    ctx = wr.WhisperContext(path4)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language(lang)
+    memo = ctx.create_batch_state(1, 1, 1)
+    memo.set_window_cache(16)
+    for secs in lengths:
+        pcm = full[: secs * 16000]
+        memo.full_batch(fp, [pcm])
+        if secs >= 77:
+            om = oracle.OracleModel(path4); ost = oracle.OracleState(om)
+            ref = ost.full(_oracle_params(oracle, fp, lang=None, beam_candidates_topk=1), pcm)
+            b = memo.batch_segments(0)
+            assert _same(b, ref), (secs, [x.tokens[:6] for x in b[:3]], [r["tokens"][:6] for r in ref[:3]])
+            ost.close(); om.close()
+    assert memo.window_cache_stats()["hits"] >= 2
+    memo.free(); ctx.free()
 
 
 def test_two_states_on_two_threads(wr, model_path):

@@ -200,4 +200,8 @@ def test_decoder_pass_at_full_row_capacity_small_widths(wr, oracle, model_path, 
     # and the cache it left behind serves the next position
     nxt = st.decode([1234], 250)
     assert float(np.abs(nxt - ost.decode([1234], 250, 0)[0]).max()) <= 1e-2
+    # the same prefix in a pass of 8 rows (split-K GEMMs with their summing consumers) and of 250 rows (fused epilogues
+    # accumulating slice by slice): the two paths make the same additions in the same order, so the logits are the same bits
+    short = st.decode_logits_all(toks[:8], 0)
+    assert np.array_equal(short, lgot[:8]), float(np.abs(short - lgot[:8]).max())
     st.free(); ctx.free(); ost.close(); om.close()
