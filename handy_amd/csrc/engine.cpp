@@ -46,6 +46,14 @@ void PinnedBuf::release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 // epilogue, which accumulates K slice by slice in the same order -- the two paths give the same bits, so the threshold is
 // a pure speed choice (WMI_SPLIT_ROWS overrides it for experiments): at 320 rows the partial sums of ten slices are five
 // times the weight bytes.
+static int spin_wait_us() {            // WMI_SPIN_US: how long a decoder pass polls for its results before it blocks (0: block at once)
+    static const int v = [] { const char *e = getenv("WMI_SPIN_US"); return e ? atoi(e) : 2000; }();
+    return v;
+}
+static bool few_rows_path() {          // WMI_FEW_ROWS=0 turns the few-row kernels off (A/B measurements)
+    static const bool v = [] { const char *e = getenv("WMI_FEW_ROWS"); return !e || atoi(e) != 0; }();
+    return v;
+}
 static size_t split_max_rows() {
     static const size_t v = [] { const char *e = getenv("WMI_SPLIT_ROWS"); return e ? (size_t)atoi(e) : (size_t)64; }();
     return v;
@@ -458,10 +466,28 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         PROF(WMI_K_DEC_OTHER, ln_bytes, splitk_residual_ln(dx_.as<float>(), ws, splits, bias, lw, lb, out, R, d, gather, n_out, stream_));
         return true;
     };
-    if (fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), model->dec[0].ln1_w, model->dec[0].ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
+    // Passes of at most 16 rows: one launch per projection (LayerNorm in its prologue, bias / residual / GELU in its epilogue),
+    // 8 launches per layer instead of 12-14; same bits as the other two paths.
+    const bool few_rows = few_rows_path() && gemm_rows_ok(R, d, d, true) && gemm_rows_ok(R, d, 4 * d, false);
+    if (fused_ln && !few_rows) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), model->dec[0].ln1_w, model->dec[0].ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
     for (int l = 0; l < Ld_; l++) {
         const DecLayer &D = model->dec[l];
         f16 *kl = kp + l * layer_stride_, *vl = vp + l * layer_stride_;
+        if (few_rows) {
+            float *x = dx_.as<float>();
+            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_rows_ln_dec_qkv(x, D.ln1_w, D.ln1_b, D.wqkv, R, d, H_, dq_.as<f16>(), kl, vl, D.bqkv, d_rows, stream_));
+            PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(dq_.as<f16>(), kl, vl, d_bt, d_rows, R, d, H_, datt_.as<f16>(), stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(datt_.as<f16>(), d, D.wo, R, d, d, x, d, D.bo, stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_ln_f16(x, D.lnx_w, D.lnx_b, D.xq, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_));
+            if (mq && max_group > 1)
+                PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp, NG, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
+            else
+                PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp, NG, max_group, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(datt_.as<f16>(), d, D.xo, R, d, d, x, d, D.bxo, stream_));
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_ln_f16(x, D.ln2_w, D.ln2_b, D.fc1, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_));
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_residual(dhid_.as<f16>(), 4 * d, D.fc2, R, d, 4 * d, x, d, D.b2, stream_));
+            continue;
+        }
         if (!fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln1_w, D.ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
         if (s_qkv > 1) {
             PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_splitk(dxn_.as<f16>(), d, D.wqkv, d, R, 3 * d, d, s_qkv, ws, splitk_ws_.cap, stream_));
@@ -504,7 +530,7 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         }
     }
     if (L > 0) {
-        if (!fused_ln) PROF(WMI_K_DEC_OTHER, (double)L * d * 6, layer_norm(dx_.as<float>(), model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), nullptr, L, d, d_gather, stream_));
+        if (!fused_ln || few_rows) PROF(WMI_K_DEC_OTHER, (double)L * d * 6, layer_norm(dx_.as<float>(), model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), nullptr, L, d, d_gather, stream_));
         PROF(WMI_K_DEC_GEMM, 2.0 * Vp_ * d + 4.0 * L * Vp_, gemm_f32(dxl_.as<f16>(), d, model->d_te, d, L, Vp_, d, logits_.as<float>(), Vp_, nullptr, stream_));
         if (logits_all_out) WMI_HIP_OK(hipMemcpy2DAsync(logits_all_out, sizeof(float) * V_, logits_.p, sizeof(float) * Vp_, sizeof(float) * V_, L, hipMemcpyDeviceToHost, stream_));
         if (want_raw_logits_host) WMI_HIP_OK(hipMemcpyAsync(logits_host_.data(), logits_.as<float>() + (size_t)(L - 1) * Vp_, sizeof(float) * V_, hipMemcpyDeviceToHost, stream_));
@@ -537,6 +563,14 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         if (any_probs) WMI_HIP_OK(hipMemcpyAsync(probs_host_.p, probs_.p, sizeof(float) * (size_t)L * V_, hipMemcpyDeviceToHost, stream_));
     }
     const double t_launched = now_ms();
+    // The end of a pass is on every token's critical path: poll the stream for a while (a blocking wait wakes up tens of
+    // microseconds after the GPU is done, a tenth of a one-clip pass) before falling back to the blocking wait.
+    if (spin_wait_us() > 0) {
+        const double t_end = t_launched + spin_wait_us() * 1e-3;
+        hipError_t q;
+        while ((q = hipStreamQuery(stream_)) == hipErrorNotReady && now_ms() < t_end) {}
+        if (q != hipSuccess && q != hipErrorNotReady) { log_msg(2, "decoder pass: %s\n", hipGetErrorString(q)); return false; }
+    }
     WMI_HIP_OK(hipStreamSynchronize(stream_));
     t_dec_launch_ms += t_launched - t_pass0; t_dec_wait_ms += now_ms() - t_launched; n_passes++;
     n_decode += R;

@@ -953,6 +953,234 @@ bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, i
     return hipGetLastError() == hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------------ few-row GEMM with a LayerNorm prologue
+// Decoder passes of at most 16 rows (one clip, its beams) are a chain of dependent launches of a few
+// microseconds each, and their cost is the number of launches. This kernel is one launch per projection with nothing
+// before or after it: a workgroup owns 16 output columns over the whole K and all rows,
+//   * LN: it first normalises every row itself (layer_norm_kernel's arithmetic, operation for operation; the rows are a
+//     few KB and L2-resident, so every workgroup redoing them is cheaper than a launch) and keeps the f16 result in LDS
+//     (only the rows the pass has: one clip is one row, and three workgroups then fit a CU);
+//     otherwise the f16 activation fragments go global -> registers;
+//   * its four or eight waves share the K-slices of the split-K path (slice s to wave s mod 4 / 8), each wave streaming its weight
+//     fragments global -> registers two chunks of eight 32-wide steps ahead -- no LDS round trip, no barrier in the loop;
+//   * the per-slice sums meet in LDS and are added in slice order, then the usual epilogue functor runs.
+// Same operand order per MFMA, same chain per slice, same fold order as gemm_skinny_kernel + its consumers and as the
+// kVSplit 64x64 kernel: the three paths give the same bits.
+template <int RT, int NWV, bool LN, class Epi>
+__global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__restrict__ x, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
+                                                        const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
+                                                        int R, int K, int per_slice, int nslice, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = 8;                                          // 32-wide K-steps per register chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4, n0 = blockIdx.x * 16;
+    f32x4 *part = (f32x4 *)smem;                                   // [slice][row tile][lane]
+    char *act = smem + (size_t)nslice * RT * 1024;                 // LN: [R rows][K halfs + 8]: rows 16 B apart in the banks
+    const int stride = K * 2 + 16;
+    const f16 *wp = W + (long)(n0 + fr) * ldw + fq * 8;
+    const f16 *ap = LN ? nullptr : A + (long)fr * lda + fq * 8;
+    const int psc = (per_slice + CH - 1) / CH;                      // chunks per slice
+    const int my_slices = wave < nslice ? (nslice - wave + NWV - 1) / NWV : 0;
+    const int nchunk = my_slices * psc;
+    constexpr int AR = LN ? 1 : RT, AC = LN ? 1 : CH;
+    f16x8 wa[CH], wb[CH], aa[AR][AC], ab[AR][AC];
+    f32x4 acc[RT];
+    // chunk q of this wave: slice wave + NWV*(q / psc), steps t0 .. t0 + n - 1
+    auto locate = [&](int q, int &si, int &ci, int &n) {
+        si = q / psc; ci = q - si * psc;
+        n = min(CH, per_slice - ci * CH);
+        return (wave + NWV * si) * per_slice + ci * CH;
+    };
+    auto load = [&](f16x8 (&wr)[CH], f16x8 (&ar)[AR][AC], int q) {
+        int si, ci, n;
+        const int t0 = locate(q, si, ci, n);
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+            if (i < n) {
+                wr[i] = *(const f16x8 *)(wp + (long)(t0 + i) * 32);
+                if constexpr (!LN) {
+#pragma unroll
+                    for (int j = 0; j < RT; j++) {               // rows past the pass are not fetched (one clip: 1 row of the tile's 16)
+                        ar[j][i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        if (j * 16 + fr < R) ar[j][i] = *(const f16x8 *)(ap + (long)j * 16 * lda + (long)(t0 + i) * 32);
+                    }
+                }
+            }
+    };
+    auto compute = [&](f16x8 (&wr)[CH], f16x8 (&ar)[AR][AC], int q) {
+        int si, ci, n;
+        const int t0 = locate(q, si, ci, n);
+        if (ci == 0) {
+#pragma unroll
+            for (int j = 0; j < RT; j++) acc[j] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+            if (i < n) {
+#pragma unroll
+                for (int j = 0; j < RT; j++) {
+                    f16x8 fa;
+                    if constexpr (LN) {
+                        fa = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        if (j * 16 + fr < R) fa = *(const f16x8 *)(act + (size_t)(j * 16 + fr) * stride + ((t0 + i) * 32 + fq * 8) * 2);
+                    } else fa = ar[j][i];
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[i], fa, acc[j], 0, 0, 0);
+                }
+            }
+        if (ci == psc - 1) {
+            const int sl = wave + NWV * si;
+#pragma unroll
+            for (int j = 0; j < RT; j++) part[(sl * RT + j) * 64 + lane] = acc[j];
+        }
+    };
+    // A projection whose K is one slice is one accumulation chain, i.e. one wave's work; streaming its weights through that
+    // wave's registers alone would take K/256 dependent round trips. Then all waves fetch the workgroup's 16 weight rows
+    // (requested here, before the LayerNorm) and park them in LDS beside the activations; wave 0 multiplies from LDS.
+    const bool staged_w = LN && nslice == 1 && K <= 1280;
+    char *wl = act + (size_t)R * stride;
+    constexpr int WP = 1280 / 8 * 16 / (64 * NWV);                 // 16-byte pieces per thread at the widest K
+    f16x8 wtmp[LN ? WP : 1];
+    if constexpr (LN) {
+        if (staged_w) {
+            const int per_row = K >> 3;
+#pragma unroll
+            for (int i = 0; i < WP; i++) {
+                const int p = tid + 64 * NWV * i;
+                if (p < 16 * per_row) { const int r = p / per_row, c = p - r * per_row; wtmp[i] = *(const f16x8 *)(W + (long)(n0 + r) * ldw + c * 8); }
+            }
+        }
+    }
+    if (!staged_w && nchunk > 0) load(wa, aa, 0);          // the first weight chunk is on its way while the rows are normalised
+    if constexpr (LN) {
+        const int nch = K >> 2;
+        constexpr int RW = RT * 16 / NWV;                          // rows per wave: row = wave + NWV * rr
+        f32x4 v[RW][5];
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) {                          // every row of the wave requested before the first is reduced
+            const int row = wave + NWV * rr;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int c = lane + 64 * i;
+                v[rr][i] = f32x4{0, 0, 0, 0};
+                if (c < nch && row < R) v[rr][i] = *((const f32x4 *)(x + (long)row * K) + c);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) {
+            const int row = wave + NWV * rr;
+            char *dst = act + (size_t)row * stride;
+            if (row >= R) continue;                                // rows past the pass have no LDS row: their operand is zero
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; i++) sum += (v[rr][i][0] + v[rr][i][1]) + (v[rr][i][2] + v[rr][i][3]);
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float)K;
+            float sq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int c = lane + 64 * i;
+                if (c < nch) { v[rr][i] -= mean; sq += (v[rr][i][0] * v[rr][i][0] + v[rr][i][1] * v[rr][i][1]) + (v[rr][i][2] * v[rr][i][2] + v[rr][i][3] * v[rr][i][3]); }
+            }
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            const float scale = 1.0f / sqrtf(sq / (float)K + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
+                    const f32x4 ww = *(const f32x4 *)(ln_w + 4 * c), bb = *(const f32x4 *)(ln_b + 4 * c);
+                    f32x4 y;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) y[k] = v[rr][i][k] * scale * ww[k] + bb[k];
+                    *(f16x4 *)(dst + 8 * c) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+                }
+            }
+        }
+        if (staged_w) {
+            const int per_row = K >> 3;
+#pragma unroll
+            for (int i = 0; i < WP; i++) {
+                const int p = tid + 64 * NWV * i;
+                if (p < 16 * per_row) { const int r = p / per_row, c = p - r * per_row; *(f16x8 *)(wl + (size_t)r * stride + c * 16) = wtmp[i]; }
+            }
+        }
+        __syncthreads();
+        if (staged_w) {
+            if (wave == 0) {
+#pragma unroll
+                for (int j = 0; j < RT; j++) acc[j] = f32x4{0, 0, 0, 0};
+                for (int t = 0; t < (K >> 5); t++) {
+                    const f16x8 fw = *(const f16x8 *)(wl + (size_t)fr * stride + (t * 32 + fq * 8) * 2);
+#pragma unroll
+                    for (int j = 0; j < RT; j++) {
+                        f16x8 fa = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (j * 16 + fr < R) fa = *(const f16x8 *)(act + (size_t)(j * 16 + fr) * stride + (t * 32 + fq * 8) * 2);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw, fa, acc[j], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RT; j++) part[j * 64 + lane] = acc[j];
+            }
+        }
+    }
+    for (int q = 0; q < (staged_w ? 0 : nchunk); q += 2) {
+        if (q + 1 < nchunk) load(wb, ab, q + 1);
+        compute(wa, aa, q);
+        if (q + 2 < nchunk) load(wa, aa, q + 2);
+        if (q + 1 < nchunk) compute(wb, ab, q + 1);
+    }
+    __syncthreads();
+    if (wave < RT) {
+        const int j = wave;
+        f32x4 a = part[j * 64 + lane];
+        for (int sl = 1; sl < nslice; sl++) a += part[(sl * RT + j) * 64 + lane];
+        const int m = j * 16 + fr;
+        if (m < R) epi(m, n0 + fq * 4, a);
+    }
+}
+
+// Rows, widths and depths the few-row kernel takes: up to 16 rows (one MFMA row tile; with two, a workgroup pulls twice
+// its weight bytes in activation fragments and the split-K path is faster: 259 against 224 ms per step on 32 clips of
+// Whisper small), K a multiple of 64, N of 16; with the LayerNorm prologue K is the model width (<= 1280).
+bool gemm_rows_ok(int R, int N, int K, bool ln) {
+    return R >= 1 && R <= 16 && N % 16 == 0 && K % BK == 0 && K <= 8192 && (!ln || K <= 1280);
+}
+template <int RT, int NWV, bool LN, class Epi>
+static bool launch_rows_rt(const float *x, const float *ln_w, const float *ln_b, const f16 *A, long lda, const f16 *W, long ldw, int R, int N, int K, const Epi &epi, hipStream_t st) {
+    const int ns = skinny_steps(N, K), per_slice = ns ? ns * 2 : K / 32, nslice = (K / 32) / per_slice;
+    if (nslice < 1 || nslice > 16 || nslice * per_slice != K / 32) { log_msg(2, "gemm_rows: bad slicing of K=%d\n", K); return false; }
+    const size_t lds = (size_t)nslice * RT * 1024 + (LN ? (size_t)R * (K * 2 + 16) : 0) + (LN && nslice == 1 && K <= 1280 ? (size_t)16 * (K * 2 + 16) : 0);
+    if (lds > 160 * 1024) { log_msg(2, "gemm_rows: %zu bytes of LDS\n", lds); return false; }
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (lds > 64 * 1024 && !((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        if (hipFuncSetAttribute((const void *)gemm_rows_kernel<RT, NWV, LN, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        attr_set.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((gemm_rows_kernel<RT, NWV, LN, Epi>), dim3(N / 16), dim3(64 * NWV), lds, st, x, ln_w, ln_b, A, lda, W, ldw, R, K, per_slice, nslice, epi);
+    return hipGetLastError() == hipSuccess;
+}
+template <bool LN, class Epi>
+static bool launch_rows(const float *x, const float *ln_w, const float *ln_b, const f16 *A, long lda, const f16 *W, long ldw, int R, int N, int K, const Epi &epi, hipStream_t st) {
+    if (!gemm_rows_ok(R, N, K, LN)) { log_msg(2, "gemm_rows: unsupported shape R=%d N=%d K=%d\n", R, N, K); return false; }
+    // eight waves where the K-slices give every one of them work: twice the weight bytes in flight per workgroup
+    const int ns = skinny_steps(N, K);
+    if (ns && K / BK / ns >= 8) return launch_rows_rt<1, 8, LN, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st);
+    return launch_rows_rt<1, 4, LN, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st);
+}
+// q, K/V pages <- LayerNorm(x) Wqkv^T + b
+bool gemm_rows_ln_dec_qkv(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st) {
+    return launch_rows<true>(x, ln_w, ln_b, nullptr, 0, W, d, R, 3 * d, d, EpiDecQKV{q, kc, vc, bias, rows, d, H}, st);
+}
+// out <- f16(act((LayerNorm(x) W^T + b) * scale))
+bool gemm_rows_ln_f16(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st) {
+    return launch_rows<true>(x, ln_w, ln_b, nullptr, 0, W, K, R, N, K, EpiF16{out, ldc, bias, gelu, scale}, st);
+}
+// x += A W^T + b
+bool gemm_rows_residual(const f16 *A, long lda, const f16 *W, int R, int N, int K, float *x, long ldc, const float *bias, hipStream_t st) {
+    return launch_rows<false>(nullptr, nullptr, nullptr, A, lda, W, K, R, N, K, EpiResidual{x, ldc, bias}, st);
+}
+
 #ifdef WMI_HARNESS
 bool gemm_read_stamps(unsigned long long *out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * n) == hipSuccess;

@@ -135,7 +135,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("WMI_LIB_PATH") or LIB_PATH          # WMI_LIB_PATH: another build of the library (A/B runs)
     if not os.path.exists(p):
         raise WhisperError(f"InitError: {p} is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(p)

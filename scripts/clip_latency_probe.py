@@ -1,0 +1,27 @@
+"""One 30 s clip end to end through whisper_full (greedy, 64 forced tokens): wall time per call and where the host
+spends it (launching the decoder passes, waiting for them). Usage: clip_latency_probe.py [arch ...]"""
+import json, os, sys, tempfile, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from handy_amd import ggml_file as gf, whisper_rs as wr
+from handy_amd.synth import synth_pcm
+
+wr.load_library()
+out = {}
+for arch in sys.argv[1:] or ["tiny.en", "large-v3-turbo"]:
+    p = os.path.join(tempfile.mkdtemp(), arch + ".bin")
+    gf.write_synthetic_model(p, arch, seed=0, decisive=2.0)
+    ctx = wr.WhisperContext(p); st = ctx.create_batch_state(1, 1, 1)
+    st.set_force_tokens(64)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_no_timestamps(True); fp.set_language("en")
+    pcm = synth_pcm(5, 30 * 16000)
+    st.full_batch(fp, [pcm])
+    walls = []
+    h0 = st.host_timings()
+    for _ in range(5):
+        t = time.perf_counter(); st.full_batch(fp, [pcm]); walls.append((time.perf_counter() - t) * 1e3)
+    h1 = st.host_timings()
+    d = {k: (h1[k] - h0[k]) / 5 for k in h0}
+    out[arch] = {"wall_ms": sorted(walls)[2], "per_call": d, "us_per_pass": 1e3 * d["decode_ms"] / max(1.0, d["passes"]),
+                 "spin_us": os.environ.get("WMI_SPIN_US", "default"), "few_rows": os.environ.get("WMI_FEW_ROWS", "default")}
+    print(arch, json.dumps(out[arch]), flush=True)
+    st.free(); ctx.free()

@@ -16,7 +16,7 @@ for arch in sys.argv[1:] or ["mini", "mini768"]:
     rng = np.random.default_rng(17)
     toks = [50257] + [int(t) for t in rng.integers(0, 50000, size=249)]
     long = st.decode_logits_all(toks, 0)
-    for n in (1, 8, 64, 65, 128, 200):
+    for n in (1, 8, 16, 17, 32, 33, 64, 65, 128, 200):
         short = st.decode_logits_all(toks[:n], 0)
         print(arch, "split<=", os.environ.get("WMI_SPLIT_ROWS", "default"), "rows", n, "max diff vs 250-row pass", float(np.abs(short - long[:n]).max()), flush=True)
     st.free(); ctx.free()

@@ -200,8 +200,10 @@ def test_decoder_pass_at_full_row_capacity_small_widths(wr, oracle, model_path, 
     # and the cache it left behind serves the next position
     nxt = st.decode([1234], 250)
     assert float(np.abs(nxt - ost.decode([1234], 250, 0)[0]).max()) <= 1e-2
-    # the same prefix in a pass of 8 rows (split-K GEMMs with their summing consumers) and of 250 rows (fused epilogues
-    # accumulating slice by slice): the two paths make the same additions in the same order, so the logits are the same bits
-    short = st.decode_logits_all(toks[:8], 0)
-    assert np.array_equal(short, lgot[:8]), float(np.abs(short - lgot[:8]).max())
+    # the same prefix in passes of 1 .. 16 rows (one launch per projection with the LayerNorm in its prologue),
+    # 17 .. 64 rows (split-K GEMMs with their summing consumers) and more (fused epilogues accumulating
+    # slice by slice): the three paths make the same additions in the same order, so the logits are the same bits
+    for n in (1, 3, 8, 16, 17, 64, 65):
+        short = st.decode_logits_all(toks[:n], 0)
+        assert np.array_equal(short, lgot[:n]), (n, float(np.abs(short - lgot[:n]).max()))
     st.free(); ctx.free(); ost.close(); om.close()
