@@ -816,12 +816,6 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 4: return launch<256, 128, 4, 2, 2, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 5: return launch<128, 256, 2, 4, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 6: return launch<64, 64, 2, 2, 4, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
-        case 60: return launch<64, 64, 2, 2, 8, EpiF16>(A, lda, W, ldw, M, N, K, e, st);         // deeper LDS-DMA queues for the decoder's latency-bound shapes
-        case 61: return launch<64, 64, 2, 2, 6, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
-        case 62: return launch<64, 64, 2, 2, 5, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
-        case 63: return launch<64, 32, 2, 2, 8, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
-        case 64: return launch<32, 64, 2, 2, 8, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
-        case 65: return launch<64, 64, 2, 2, 10, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 7: return launch<128, 64, 2, 2, 4, EpiF16>(A, lda, W, ldw, M, N, K, e, st);
         case 9: return launch<256, 256, 2, 4, 2, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);    // LDS-DMA issue spread over the MFMA groups
         case 10: return launch<256, 128, 4, 2, 3, EpiF16, 8>(A, lda, W, ldw, M, N, K, e, st);
