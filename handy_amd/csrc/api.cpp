@@ -376,6 +376,12 @@ int wmi_get_cross_kv(struct whisper_state *s, int layer, float *k, float *v) {
     Engine *e = ENG(s); return e && k && v ? e->get_cross_kv(layer, k, v) : -1;
     WMI_CATCH(-1)
 }
+void wmi_set_quant_resident(int on) { wmi::set_quant_resident(on != 0); }
+int wmi_set_quant_decode(struct whisper_state *s, int on) {
+    Engine *e = ENG(s); if (!e) return -1;
+    e->quant_decode = on != 0;
+    return 0;
+}
 int wmi_get_host_timings(struct whisper_state *s, double *out) {
     Engine *e = ENG(s); if (!e || !out) return -1;
     out[0] = e->t_mel_ms; out[1] = e->t_encode_ms; out[2] = e->t_decode_ms; out[3] = e->t_dec_launch_ms; out[4] = e->t_dec_wait_ms; out[5] = (double)e->n_passes;
@@ -455,6 +461,33 @@ int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_block
         hipMemcpy(out, dout, (size_t)n_blocks * 64, hipMemcpyDeviceToHost) == hipSuccess)
         rc = 0;
     (void)hipFree(db); (void)hipFree(dout);
+    return rc;
+    WMI_CATCH(-1)
+}
+
+// Test hook: y = A W^T for `rows` (<= 16) activation rows through the few-row GEMM kernel, once with W read as the given ggml
+// blocks (out_blocks) and once with W as their load-time fp16 expansion (out_f16); fp32 [rows][N] each.
+int wmi_debug_quant_rows(int ggml_type, const void *blocks, int N, int K, const unsigned short *a_f16, int rows, float *out_blocks, float *out_f16) {
+    WMI_TRY
+    const int bb = wmi::quant_block_bytes(ggml_type);
+    if (!bb || !blocks || !a_f16 || !out_blocks || !out_f16 || N <= 0 || K <= 0 || K % 64 || !wmi::gemm_rows_ok(rows, N, K, false)) return -1;
+    const size_t nblk = (size_t)N * K / 32, qb = ggml_type == 8 ? 32 : 16;
+    void *db = nullptr, *qs = nullptr, *dm = nullptr, *qh = nullptr; f16 *w16 = nullptr, *da = nullptr; float *x = nullptr, *zero_bias = nullptr;
+    int rc = -1;
+    if (hipMalloc(&db, nblk * bb + 256) == hipSuccess && hipMalloc(&w16, nblk * 64 + 256) == hipSuccess && hipMalloc(&qs, nblk * qb + 256) == hipSuccess &&
+        hipMalloc(&dm, nblk * 4 + 256) == hipSuccess && hipMalloc(&qh, nblk * 4 + 256) == hipSuccess && hipMalloc(&da, (size_t)256 * K * 2) == hipSuccess &&
+        hipMalloc(&x, (size_t)2 * rows * N * 4 + 256) == hipSuccess && hipMalloc(&zero_bias, (size_t)N * 4 + 256) == hipSuccess &&
+        hipMemset(da, 0, (size_t)256 * K * 2) == hipSuccess && hipMemset(x, 0, (size_t)2 * rows * N * 4) == hipSuccess && hipMemset(zero_bias, 0, (size_t)N * 4) == hipSuccess &&
+        hipMemcpy(db, blocks, nblk * bb, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(da, a_f16, (size_t)rows * K * 2, hipMemcpyHostToDevice) == hipSuccess &&
+        wmi::expand_blocks_f16(db, ggml_type, (long)nblk, w16, nullptr) && wmi::quant_repack(db, ggml_type, (long)nblk, qs, (unsigned *)dm, (unsigned *)qh, nullptr)) {
+        wmi::QuantW q; q.qs = (const unsigned char *)qs; q.dm = (const unsigned *)dm; q.qh = (const unsigned *)qh; q.ttype = ggml_type;
+        if (wmi::gemm_rows_residual(da, K, w16, rows, N, K, x, N, zero_bias, nullptr, &q) &&
+            wmi::gemm_rows_residual(da, K, w16, rows, N, K, x + (size_t)rows * N, N, zero_bias, nullptr, nullptr) && hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(out_blocks, x, (size_t)rows * N * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(out_f16, x + (size_t)rows * N, (size_t)rows * N * 4, hipMemcpyDeviceToHost) == hipSuccess)
+            rc = 0;
+    }
+    for (void *p : {db, (void *)w16, qs, dm, qh, (void *)da, (void *)x, (void *)zero_bias}) (void)hipFree(p);
     return rc;
     WMI_CATCH(-1)
 }

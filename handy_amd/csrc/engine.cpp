@@ -475,17 +475,18 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         f16 *kl = kp + l * layer_stride_, *vl = vp + l * layer_stride_;
         if (few_rows) {
             float *x = dx_.as<float>();
-            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_rows_ln_dec_qkv(x, D.ln1_w, D.ln1_b, D.wqkv, R, d, H_, dq_.as<f16>(), kl, vl, D.bqkv, d_rows, stream_));
+            auto qw = [&](const QuantW &q) -> const QuantW * { return quant_decode && q.ttype ? &q : nullptr; };
+            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_rows_ln_dec_qkv(x, D.ln1_w, D.ln1_b, D.wqkv, R, d, H_, dq_.as<f16>(), kl, vl, D.bqkv, d_rows, stream_, qw(D.q_wqkv)));
             PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(dq_.as<f16>(), kl, vl, d_bt, d_rows, R, d, H_, datt_.as<f16>(), stream_));
-            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(datt_.as<f16>(), d, D.wo, R, d, d, x, d, D.bo, stream_));
-            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_ln_f16(x, D.lnx_w, D.lnx_b, D.xq, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(datt_.as<f16>(), d, D.wo, R, d, d, x, d, D.bo, stream_, qw(D.q_wo)));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_ln_f16(x, D.lnx_w, D.lnx_b, D.xq, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_, qw(D.q_xq)));
             if (mq && max_group > 1)
                 PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp, NG, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
             else
                 PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp, NG, max_group, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
-            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(datt_.as<f16>(), d, D.xo, R, d, d, x, d, D.bxo, stream_));
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_ln_f16(x, D.ln2_w, D.ln2_b, D.fc1, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_));
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_residual(dhid_.as<f16>(), 4 * d, D.fc2, R, d, 4 * d, x, d, D.b2, stream_));
+            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(datt_.as<f16>(), d, D.xo, R, d, d, x, d, D.bxo, stream_, qw(D.q_xo)));
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_ln_f16(x, D.ln2_w, D.ln2_b, D.fc1, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_, qw(D.q_fc1)));
+            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_residual(dhid_.as<f16>(), 4 * d, D.fc2, R, d, 4 * d, x, d, D.b2, stream_, qw(D.q_fc2)));
             continue;
         }
         if (!fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln1_w, D.ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));

@@ -132,6 +132,7 @@ public:
 
     // profiling
     bool profiling = false;
+    bool quant_decode = true;           // few-row decode passes read the decoder weights as the file's blocks where the model holds them
     unsigned profile_mask = ~0u;        // bit per wmi_kernel_class: which classes get event pairs while profiling is on
     wmi_kernel_stat stats[WMI_K_COUNT]{};
     void collect_stats();

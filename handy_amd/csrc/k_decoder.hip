@@ -38,13 +38,16 @@ __device__ __forceinline__ void attn_init(AttnAcc &s) { s.m = -INFINITY; s.l = 0
 __device__ __forceinline__ void attn_step(AttnAcc &s, const float *q, f16x8 k, f16x8 v) {
     float d0 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; i++) d0 += q[i] * (float)k[i];
+    for (int i = 0; i < 8; i++) d0 = __builtin_fmaf(q[i], (float)k[i], d0);
     d0 += __shfl_xor(d0, 1); d0 += __shfl_xor(d0, 2); d0 += __shfl_xor(d0, 4);
     const float mn = fmaxf(s.m, d0);
     const float alpha = __expf(s.m - mn), p = __expf(d0 - mn);
-    s.l = s.l * alpha + p;
+    // the fused multiply-adds are written out: left to the compiler, "a * alpha + p * v" is fused around either product, and
+    // the choice differed between instantiations of the kernels below (a row's result then depended, in its last bit and
+    // once in a few thousand outputs, on how many rows shared its pass)
+    s.l = __builtin_fmaf(s.l, alpha, p);
 #pragma unroll
-    for (int i = 0; i < 8; i++) s.a[i] = s.a[i] * alpha + p * (float)v[i];
+    for (int i = 0; i < 8; i++) s.a[i] = __builtin_fmaf(p, (float)v[i], s.a[i] * alpha);
     s.m = mn;
 }
 // merge with the lane `mask` away (same head-dim slice, other keys); a group that saw no key has m = -inf, l = 0
@@ -52,9 +55,9 @@ __device__ __forceinline__ void attn_merge_xor(AttnAcc &s, int mask) {
     const float om = __shfl_xor(s.m, mask), ol = __shfl_xor(s.l, mask);
     const float mn = fmaxf(s.m, om);
     const float fa = s.m == -INFINITY ? 0.0f : __expf(s.m - mn), fb = om == -INFINITY ? 0.0f : __expf(om - mn);
-    s.l = s.l * fa + ol * fb;
+    s.l = __builtin_fmaf(ol, fb, s.l * fa);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const float oa = __shfl_xor(s.a[i], mask); s.a[i] = s.a[i] * fa + oa * fb; }
+    for (int i = 0; i < 8; i++) { const float oa = __shfl_xor(s.a[i], mask); s.a[i] = __builtin_fmaf(oa, fb, s.a[i] * fa); }
     s.m = mn;
 }
 
@@ -73,9 +76,9 @@ __device__ __forceinline__ void attn_block_finish(AttnAcc &s, float (*red)[8][10
         for (int w = 0; w < 4; w++) {
             const float mw = red[w][tid][0];
             const float f = mw == -INFINITY ? 0.0f : __expf(mw - mn);
-            l += red[w][tid][1] * f;
+            l = __builtin_fmaf(red[w][tid][1], f, l);
 #pragma unroll
-            for (int i = 0; i < 8; i++) a[i] += red[w][tid][2 + i] * f;
+            for (int i = 0; i < 8; i++) a[i] = __builtin_fmaf(red[w][tid][2 + i], f, a[i]);
         }
         const float inv = 1.0f / l;
         f16x8 o;

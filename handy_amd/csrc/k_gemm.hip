@@ -960,10 +960,64 @@ bool gemm_splitk(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, i
 //   * the per-slice sums meet in LDS and are added in slice order, then the usual epilogue functor runs.
 // Same operand order per MFMA, same chain per slice, same fold order as gemm_skinny_kernel + its consumers and as the
 // kVSplit 64x64 kernel: the three paths give the same bits.
-template <int RT, int NWV, bool LN, class Epi>
+// One lane's weight operand of one 32-wide K-step as it travels from memory to the MFMA: 8 halfs, or -- QT = the ggml tensor
+// type of a block-quantised matrix -- its 8 quants, the block's {d, m} word and fifth-bit word. dequant8 turns the latter
+// into the fp16 values the load-time expansion (expand_blocks_kernel) writes, bit for bit: quant x d (+ m, or - zero x d)
+// is exact in fp32 for quants of at most 8 bits and an fp16 scale, so one fused multiply-add per value rounds exactly
+// once where the expansion's multiply (exact) and add round once -- then the same conversion to fp16. (Only the sign of
+// a zero weight can differ, which no sum of products can see.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int QT>
+__device__ __forceinline__ u32x4 load_wfrag(const f16 *W, long ldw, const QuantW &qw, int nb, int row, int t, int quad) {
+    if constexpr (QT == 0) {
+        return *(const u32x4 *)(W + (long)row * ldw + t * 32 + quad * 8);
+    } else {
+        const long blk = (long)row * nb + t;
+        u32x4 r;
+        const uint2 q = QT == 8 ? *(const uint2 *)(qw.qs + blk * 32 + quad * 8) : *(const uint2 *)(qw.qs + blk * 16 + (quad & 1) * 8);
+        r[0] = q.x; r[1] = q.y; r[2] = qw.dm[blk];
+        r[3] = (QT == 6 || QT == 7) ? qw.qh[blk] : 0u;
+        return r;
+    }
+}
+template <int QT>
+__device__ __forceinline__ f16x8 wfrag_f16(u32x4 r, int quad) {
+    if constexpr (QT == 0) {
+        return __builtin_bit_cast(f16x8, r);
+    } else {
+        const unsigned dmw = r[2];                                   // (a bit_cast straight from the vector element reads element 0 with this compiler)
+        const f16x2 dmh = __builtin_bit_cast(f16x2, dmw);
+        const float d = (float)dmh[0];
+        unsigned w0, w1;
+        float c;
+        if (QT == 8) {
+            w0 = r[0] ^ 0x80808080u; w1 = r[1] ^ 0x80808080u;       // int8 + 128 as unsigned bytes
+            c = -128.0f * d;
+        } else {
+            const int sh = (quad >> 1) * 4;                          // weights 0..15 are the low nibbles, 16..31 the high ones
+            w0 = (r[0] >> sh) & 0x0F0F0F0Fu; w1 = (r[1] >> sh) & 0x0F0F0F0Fu;
+            if (QT == 6 || QT == 7) {                                // fifth bit of weight v is bit v of the block's word
+                const unsigned hb = (r[3] >> (8 * quad)) & 0xFFu;
+                w0 |= (((hb & 0xFu) * 0x00204081u) & 0x01010101u) << 4;          // bit i -> byte i
+                w1 |= (((hb >> 4) * 0x00204081u) & 0x01010101u) << 4;
+            }
+            c = (QT == 3 || QT == 7) ? (float)dmh[1] : (QT == 6 ? -16.0f : -8.0f) * d;
+        }
+        f16x8 o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float a = __builtin_fmaf((float)((w0 >> (8 * i)) & 0xFFu), d, c), b = __builtin_fmaf((float)((w1 >> (8 * i)) & 0xFFu), d, c);
+            asm volatile("" : "+v"(a), "+v"(b));                     // the fp32 values are pinned: no mixed-precision fusion with the conversion
+            o[i] = (f16)a; o[4 + i] = (f16)b;
+        }
+        return o;
+    }
+}
+
+template <int RT, int NWV, bool LN, int QT, class Epi>
 __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__restrict__ x, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
                                                         const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
-                                                        int R, int K, int per_slice, int nslice, Epi epi) {
+                                                        int R, int K, int per_slice, int nslice, Epi epi, QuantW qw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CH = 8;                                          // 32-wide K-steps per register chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -971,13 +1025,14 @@ __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__rest
     f32x4 *part = (f32x4 *)smem;                                   // [slice][row tile][lane]
     char *act = smem + (size_t)nslice * RT * 1024;                 // LN: [R rows][K halfs + 8]: rows 16 B apart in the banks
     const int stride = K * 2 + 16;
-    const f16 *wp = W + (long)(n0 + fr) * ldw + fq * 8;
+    const int nb = K >> 5;                                         // blocks of 32 per weight row
     const f16 *ap = LN ? nullptr : A + (long)fr * lda + fq * 8;
     const int psc = (per_slice + CH - 1) / CH;                      // chunks per slice
     const int my_slices = wave < nslice ? (nslice - wave + NWV - 1) / NWV : 0;
     const int nchunk = my_slices * psc;
     constexpr int AR = LN ? 1 : RT, AC = LN ? 1 : CH;
-    f16x8 wa[CH], wb[CH], aa[AR][AC], ab[AR][AC];
+    u32x4 wa[CH], wb[CH];
+    f16x8 aa[AR][AC], ab[AR][AC];
     f32x4 acc[RT];
     // chunk q of this wave: slice wave + NWV*(q / psc), steps t0 .. t0 + n - 1
     auto locate = [&](int q, int &si, int &ci, int &n) {
@@ -985,13 +1040,13 @@ __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__rest
         n = min(CH, per_slice - ci * CH);
         return (wave + NWV * si) * per_slice + ci * CH;
     };
-    auto load = [&](f16x8 (&wr)[CH], f16x8 (&ar)[AR][AC], int q) {
+    auto load = [&](u32x4 (&wr)[CH], f16x8 (&ar)[AR][AC], int q) {
         int si, ci, n;
         const int t0 = locate(q, si, ci, n);
 #pragma unroll
         for (int i = 0; i < CH; i++)
             if (i < n) {
-                wr[i] = *(const f16x8 *)(wp + (long)(t0 + i) * 32);
+                wr[i] = load_wfrag<QT>(W, ldw, qw, nb, n0 + fr, t0 + i, fq);
                 if constexpr (!LN) {
 #pragma unroll
                     for (int j = 0; j < RT; j++) {               // rows past the pass are not fetched (one clip: 1 row of the tile's 16)
@@ -1001,7 +1056,7 @@ __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__rest
                 }
             }
     };
-    auto compute = [&](f16x8 (&wr)[CH], f16x8 (&ar)[AR][AC], int q) {
+    auto compute = [&](u32x4 (&wr)[CH], f16x8 (&ar)[AR][AC], int q) {
         int si, ci, n;
         const int t0 = locate(q, si, ci, n);
         if (ci == 0) {
@@ -1011,6 +1066,7 @@ __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__rest
 #pragma unroll
         for (int i = 0; i < CH; i++)
             if (i < n) {
+                const f16x8 fw = wfrag_f16<QT>(wr[i], fq);
 #pragma unroll
                 for (int j = 0; j < RT; j++) {
                     f16x8 fa;
@@ -1018,7 +1074,7 @@ __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__rest
                         fa = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                         if (j * 16 + fr < R) fa = *(const f16x8 *)(act + (size_t)(j * 16 + fr) * stride + ((t0 + i) * 32 + fq * 8) * 2);
                     } else fa = ar[j][i];
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[i], fa, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw, fa, acc[j], 0, 0, 0);
                 }
             }
         if (ci == psc - 1) {
@@ -1033,14 +1089,14 @@ __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__rest
     const bool staged_w = LN && nslice == 1 && K <= 1280;
     char *wl = act + (size_t)R * stride;
     constexpr int WP = 1280 / 8 * 16 / (64 * NWV);                 // 16-byte pieces per thread at the widest K
-    f16x8 wtmp[LN ? WP : 1];
+    u32x4 wtmp[LN ? WP : 1];
     if constexpr (LN) {
         if (staged_w) {
             const int per_row = K >> 3;
 #pragma unroll
             for (int i = 0; i < WP; i++) {
                 const int p = tid + 64 * NWV * i;
-                if (p < 16 * per_row) { const int r = p / per_row, c = p - r * per_row; wtmp[i] = *(const f16x8 *)(W + (long)(n0 + r) * ldw + c * 8); }
+                if (p < 16 * per_row) { const int r = p / per_row, c = p - r * per_row; wtmp[i] = load_wfrag<QT>(W, ldw, qw, nb, n0 + r, c >> 2, c & 3); }
             }
         }
     }
@@ -1094,7 +1150,7 @@ __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__rest
 #pragma unroll
             for (int i = 0; i < WP; i++) {
                 const int p = tid + 64 * NWV * i;
-                if (p < 16 * per_row) { const int r = p / per_row, c = p - r * per_row; *(f16x8 *)(wl + (size_t)r * stride + c * 16) = wtmp[i]; }
+                if (p < 16 * per_row) { const int r = p / per_row, c = p - r * per_row; *(f16x8 *)(wl + (size_t)r * stride + c * 16) = wfrag_f16<QT>(wtmp[i], c & 3); }
             }
         }
         __syncthreads();
@@ -1138,8 +1194,8 @@ __global__ __launch_bounds__(64 * NWV) void gemm_rows_kernel(const float *__rest
 bool gemm_rows_ok(int R, int N, int K, bool ln) {
     return R >= 1 && R <= 16 && N % 16 == 0 && K % BK == 0 && K <= 8192 && (!ln || K <= 1280);
 }
-template <int RT, int NWV, bool LN, class Epi>
-static bool launch_rows_rt(const float *x, const float *ln_w, const float *ln_b, const f16 *A, long lda, const f16 *W, long ldw, int R, int N, int K, const Epi &epi, hipStream_t st) {
+template <int RT, int NWV, bool LN, int QT, class Epi>
+static bool launch_rows_rt(const float *x, const float *ln_w, const float *ln_b, const f16 *A, long lda, const f16 *W, long ldw, int R, int N, int K, const Epi &epi, hipStream_t st, const QuantW &qw) {
     const int ns = skinny_steps(N, K), per_slice = ns ? ns * 2 : K / 32, nslice = (K / 32) / per_slice;
     if (nslice < 1 || nslice > 16 || nslice * per_slice != K / 32) { log_msg(2, "gemm_rows: bad slicing of K=%d\n", K); return false; }
     const size_t lds = (size_t)nslice * RT * 1024 + (LN ? (size_t)R * (K * 2 + 16) : 0) + (LN && nslice == 1 && K <= 1280 ? (size_t)16 * (K * 2 + 16) : 0);
@@ -1148,31 +1204,45 @@ static bool launch_rows_rt(const float *x, const float *ln_w, const float *ln_b,
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     if (lds > 64 * 1024 && !((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
-        if (hipFuncSetAttribute((const void *)gemm_rows_kernel<RT, NWV, LN, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void *)gemm_rows_kernel<RT, NWV, LN, QT, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL((gemm_rows_kernel<RT, NWV, LN, Epi>), dim3(N / 16), dim3(64 * NWV), lds, st, x, ln_w, ln_b, A, lda, W, ldw, R, K, per_slice, nslice, epi);
+    hipLaunchKernelGGL((gemm_rows_kernel<RT, NWV, LN, QT, Epi>), dim3(N / 16), dim3(64 * NWV), lds, st, x, ln_w, ln_b, A, lda, W, ldw, R, K, per_slice, nslice, epi, qw);
     return hipGetLastError() == hipSuccess;
 }
-template <bool LN, class Epi>
-static bool launch_rows(const float *x, const float *ln_w, const float *ln_b, const f16 *A, long lda, const f16 *W, long ldw, int R, int N, int K, const Epi &epi, hipStream_t st) {
-    if (!gemm_rows_ok(R, N, K, LN)) { log_msg(2, "gemm_rows: unsupported shape R=%d N=%d K=%d\n", R, N, K); return false; }
+template <bool LN, int QT, class Epi>
+static bool launch_rows_qt(const float *x, const float *ln_w, const float *ln_b, const f16 *A, long lda, const f16 *W, long ldw, int R, int N, int K, const Epi &epi, hipStream_t st, const QuantW &qw) {
     // eight waves where the K-slices give every one of them work: twice the weight bytes in flight per workgroup
     const int ns = skinny_steps(N, K);
-    if (ns && K / BK / ns >= 8) return launch_rows_rt<1, 8, LN, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st);
-    return launch_rows_rt<1, 4, LN, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st);
+    if (ns && K / BK / ns >= 8) return launch_rows_rt<1, 8, LN, QT, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st, qw);
+    return launch_rows_rt<1, 4, LN, QT, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st, qw);
+}
+template <bool LN, class Epi>
+static bool launch_rows(const float *x, const float *ln_w, const float *ln_b, const f16 *A, long lda, const f16 *W, long ldw, int R, int N, int K, const Epi &epi, hipStream_t st, const QuantW *qw) {
+    if (!gemm_rows_ok(R, N, K, LN)) { log_msg(2, "gemm_rows: unsupported shape R=%d N=%d K=%d\n", R, N, K); return false; }
+    const QuantW none{};
+    if (!qw || !qw->ttype) return launch_rows_qt<LN, 0, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st, none);
+    if (!qw->qs || !qw->dm || ((qw->ttype == 6 || qw->ttype == 7) && !qw->qh)) return false;
+    switch (qw->ttype) {
+        case 2: return launch_rows_qt<LN, 2, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st, *qw);
+        case 3: return launch_rows_qt<LN, 3, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st, *qw);
+        case 6: return launch_rows_qt<LN, 6, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st, *qw);
+        case 7: return launch_rows_qt<LN, 7, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st, *qw);
+        case 8: return launch_rows_qt<LN, 8, Epi>(x, ln_w, ln_b, A, lda, W, ldw, R, N, K, epi, st, *qw);
+    }
+    return false;
 }
 // q, K/V pages <- LayerNorm(x) Wqkv^T + b
-bool gemm_rows_ln_dec_qkv(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st) {
-    return launch_rows<true>(x, ln_w, ln_b, nullptr, 0, W, d, R, 3 * d, d, EpiDecQKV{q, kc, vc, bias, rows, d, H}, st);
+bool gemm_rows_ln_dec_qkv(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st, const QuantW *qw) {
+    return launch_rows<true>(x, ln_w, ln_b, nullptr, 0, W, d, R, 3 * d, d, EpiDecQKV{q, kc, vc, bias, rows, d, H}, st, qw);
 }
 // out <- f16(act((LayerNorm(x) W^T + b) * scale))
-bool gemm_rows_ln_f16(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st) {
-    return launch_rows<true>(x, ln_w, ln_b, nullptr, 0, W, K, R, N, K, EpiF16{out, ldc, bias, gelu, scale}, st);
+bool gemm_rows_ln_f16(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st, const QuantW *qw) {
+    return launch_rows<true>(x, ln_w, ln_b, nullptr, 0, W, K, R, N, K, EpiF16{out, ldc, bias, gelu, scale}, st, qw);
 }
 // x += A W^T + b
-bool gemm_rows_residual(const f16 *A, long lda, const f16 *W, int R, int N, int K, float *x, long ldc, const float *bias, hipStream_t st) {
-    return launch_rows<false>(nullptr, nullptr, nullptr, A, lda, W, K, R, N, K, EpiResidual{x, ldc, bias}, st);
+bool gemm_rows_residual(const f16 *A, long lda, const f16 *W, int R, int N, int K, float *x, long ldc, const float *bias, hipStream_t st, const QuantW *qw) {
+    return launch_rows<false>(nullptr, nullptr, nullptr, A, lda, W, K, R, N, K, EpiResidual{x, ldc, bias}, st, qw);
 }
 
 #ifdef WMI_HARNESS

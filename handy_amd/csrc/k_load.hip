@@ -82,7 +82,41 @@ __global__ __launch_bounds__(256) void expand_blocks_kernel(const unsigned short
     }
 }
 
+// The same blocks kept quantised for the decoder's few-row GEMMs, in a layout whose pieces are aligned: per block one
+// word {d, m} (m = 0 for the formats without a minimum), one word of fifth bits (5-bit formats) and the 16 nibble bytes
+// (32 int8 for Q8_0) in ggml's order. One thread per block.
+template <int TT>
+__global__ __launch_bounds__(256) void repack_blocks_kernel(const unsigned short *__restrict__ src, long n_blocks, unsigned *__restrict__ qs,
+                                                            unsigned *__restrict__ dm, unsigned *__restrict__ qh) {
+    using F = BlockFmt<TT>;
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    const unsigned short *p = src + b * (F::bytes / 2);
+    dm[b] = (unsigned)p[0] | (F::has_min ? (unsigned)p[1] << 16 : 0u);
+    if (F::has_high) qh[b] = (unsigned)p[F::qofs / 2 - 2] | ((unsigned)p[F::qofs / 2 - 1] << 16);
+    constexpr int NW = TT == 8 ? 8 : 4;                         // 32-bit words of quants per block
+#pragma unroll
+    for (int i = 0; i < NW; i++) qs[b * NW + i] = (unsigned)p[F::qofs / 2 + 2 * i] | ((unsigned)p[F::qofs / 2 + 2 * i + 1] << 16);
+}
+
 }  // namespace
+
+bool quant_repack(const void *blocks, int ttype, long n_blocks, void *qs, unsigned *dm, unsigned *qh, hipStream_t st) {
+    if (n_blocks <= 0) return true;
+    if (!quant_block_bytes(ttype) || ((uintptr_t)blocks & 1) || ((uintptr_t)qs & 3) || !dm || ((ttype == 6 || ttype == 7) && !qh)) return false;
+    const long grid = (n_blocks + 255) / 256;
+    if (grid > 0x7fffffffL) return false;
+    const unsigned short *s = (const unsigned short *)blocks;
+    unsigned *q = (unsigned *)qs;
+    switch (ttype) {
+        case 2: repack_blocks_kernel<2><<<dim3((unsigned)grid), 256, 0, st>>>(s, n_blocks, q, dm, qh); break;
+        case 3: repack_blocks_kernel<3><<<dim3((unsigned)grid), 256, 0, st>>>(s, n_blocks, q, dm, qh); break;
+        case 6: repack_blocks_kernel<6><<<dim3((unsigned)grid), 256, 0, st>>>(s, n_blocks, q, dm, qh); break;
+        case 7: repack_blocks_kernel<7><<<dim3((unsigned)grid), 256, 0, st>>>(s, n_blocks, q, dm, qh); break;
+        case 8: repack_blocks_kernel<8><<<dim3((unsigned)grid), 256, 0, st>>>(s, n_blocks, q, dm, qh); break;
+    }
+    return hipGetLastError() == hipSuccess;
+}
 
 int quant_block_bytes(int ttype) {
     switch (ttype) { case 2: return 18; case 3: return 20; case 6: return 22; case 7: return 24; case 8: return 34; }

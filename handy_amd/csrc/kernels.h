@@ -8,11 +8,21 @@ namespace wmi {
 bool gemm_f16(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st, bool dec = false);
 bool gemm_f32(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, float *out, long ldc, const float *bias, hipStream_t st);
 bool gemm_residual(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, float *x, long ldc, const float *bias, hipStream_t st, bool dec = false);
+// A [N][K] weight matrix kept block-quantised on the device (ggml tensor types 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0;
+// 32 weights per block) for the few-row decoder GEMMs, which expand the blocks in registers to the very fp16 values the
+// load-time expansion writes: a third to a half of the fp16 bytes per decoded token.
+struct QuantW {
+    const unsigned char *qs = nullptr;   // [N][K/32][16] nibble bytes, ggml order (types 2, 3, 6, 7); [N][K/32][32] int8 (type 8)
+    const unsigned *dm = nullptr;        // [N][K/32] {f16 d, f16 m}; m = 0 for the formats without a minimum
+    const unsigned *qh = nullptr;        // [N][K/32] fifth bits (types 6, 7)
+    int ttype = 0;                       // 0: not resident
+};
+bool quant_repack(const void *blocks, int ttype, long n_blocks, void *qs, unsigned *dm, unsigned *qh, hipStream_t st);
 // Few-row decoder GEMMs (<= 16 rows): one launch per projection, LayerNorm in the prologue, the split-K path's bits
 bool gemm_rows_ok(int R, int N, int K, bool ln);
-bool gemm_rows_ln_dec_qkv(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st);
-bool gemm_rows_ln_f16(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st);
-bool gemm_rows_residual(const f16 *A, long lda, const f16 *W, int R, int N, int K, float *x, long ldc, const float *bias, hipStream_t st);
+bool gemm_rows_ln_dec_qkv(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int d, int H, f16 *q, f16 *kc, f16 *vc, const float *bias, const DecRow *rows, hipStream_t st, const QuantW *qw = nullptr);
+bool gemm_rows_ln_f16(const float *x, const float *ln_w, const float *ln_b, const f16 *W, int R, int N, int K, f16 *out, long ldc, const float *bias, int gelu, float scale, hipStream_t st, const QuantW *qw = nullptr);
+bool gemm_rows_residual(const f16 *A, long lda, const f16 *W, int R, int N, int K, float *x, long ldc, const float *bias, hipStream_t st, const QuantW *qw = nullptr);
 bool gemm_conv1(const f16 *melT, int n_mel, const f16 *W, int Kpad, int M, int d, f16 *h1, const float *bias, int T2, hipStream_t st);
 bool gemm_conv2(const f16 *h1, const f16 *W, int M, int d, float *x, const float *bias, const float *pe, int T, hipStream_t st);
 bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *K, f16 *Vt, const float *bias, hipStream_t st);

@@ -3,6 +3,7 @@
 // Q5_0 variants). Quantised tensors are expanded to fp16 once, at load time: the large matrices on the device from
 // their uploaded blocks (k_load.hip), the few small vectors on the host.
 #include "model.h"
+#include <atomic>
 
 #include <math.h>
 #include <string.h>
@@ -11,6 +12,19 @@
 #include <memory>
 
 namespace wmi {
+
+// Whether block-quantised model files keep their decoder matrices resident as blocks next to the fp16 copies (for the
+// few-row decode GEMMs). Off unless asked for: the few-row kernels are bound by launch and load latency, not by weight
+// bytes, and expanding blocks in registers costs them more than the bytes save (measured: +1.4 us per projection).
+static std::atomic<int> g_quant_resident{-1};
+void set_quant_resident(bool on) { g_quant_resident.store(on ? 1 : 0); }
+bool quant_resident() {
+    const int v = g_quant_resident.load();
+    if (v >= 0) return v != 0;
+    const char *e = getenv("WMI_QUANT_RESIDENT");
+    return e && atoi(e) != 0;
+}
+
 
 static const char *k_lang[kNumLangs][2] = {
     {"en", "english"}, {"zh", "chinese"}, {"de", "german"}, {"es", "spanish"}, {"ru", "russian"}, {"ko", "korean"}, {"fr", "french"},
@@ -142,6 +156,38 @@ struct Uploader {
         }
         // the copy and the kernel both run on the null stream: the next tensor's copy waits for this one's expansion
         if (hipMemcpy(stage, t.data, bytes, hipMemcpyHostToDevice) != hipSuccess || !expand_blocks_f16(stage, t.ttype, (long)nb, dst, nullptr)) ok = false;
+    }
+    // The tensors `parts` (same block format, stacked along the rows) kept quantised: blocks through the staging buffer into the
+    // aligned layout of QuantW. Returns ttype 0 when the parts are not block-quantised alike.
+    QuantW put_quant(const std::vector<const TensorRef *> &parts) {
+        QuantW q;
+        if (!ok || parts.empty() || !parts[0]) return q;
+        const int tt = parts[0]->ttype;
+        size_t blocks = 0;
+        for (const TensorRef *t : parts) { if (!t || t->ttype != tt || !quant_block_bytes(tt) || t->n % 32) return q; blocks += t->n / 32; }
+        const size_t qb = tt == 8 ? 32 : 16;
+        const bool high = tt == 6 || tt == 7;
+        void *qs = nullptr, *dm = nullptr, *qh = nullptr;
+        if (hipMalloc(&qs, blocks * qb + 256) != hipSuccess) { log_msg(2, "load: hipMalloc of %zu bytes failed\n", blocks * qb); ok = false; return q; }
+        m->allocs.push_back(qs);
+        if (hipMalloc(&dm, blocks * 4 + 256) != hipSuccess) { ok = false; return q; }
+        m->allocs.push_back(dm);
+        if (high) { if (hipMalloc(&qh, blocks * 4 + 256) != hipSuccess) { ok = false; return q; } m->allocs.push_back(qh); }
+        m->bytes += blocks * (qb + 4 + (high ? 4 : 0));
+        size_t off = 0;
+        for (const TensorRef *t : parts) {
+            const size_t nb = t->n / 32, bytes = nb * (size_t)quant_block_bytes(tt);
+            if (bytes > stage_bytes) {
+                if (stage) { (void)hipDeviceSynchronize(); (void)hipFree(stage); stage = nullptr; stage_bytes = 0; }
+                if (hipMalloc(&stage, bytes + 256) != hipSuccess) { ok = false; return q; }
+                stage_bytes = bytes;
+            }
+            if (hipMemcpy(stage, t->data, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                !quant_repack(stage, tt, (long)nb, (char *)qs + off * qb, (unsigned *)dm + off, high ? (unsigned *)qh + off : nullptr, nullptr)) { ok = false; return q; }
+            off += nb;
+        }
+        q.qs = (const unsigned char *)qs; q.dm = (const unsigned *)dm; q.qh = (const unsigned *)qh; q.ttype = tt;
+        return q;
     }
     bool finish() {
         if (hipDeviceSynchronize() != hipSuccess) ok = false;
@@ -335,6 +381,7 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
         E.fc2 = put_f16(p + "mlp.2.weight", 4 * dd); E.b2 = put_f32(p + "mlp.2.bias", d);
     }
     M->dec.resize(hp.n_text_layer);
+    const bool keep_quant = quant_resident() && d % 64 == 0;
     {
         f16 *xkv = U.alloc_f16((size_t)hp.n_text_layer * 2 * dd);
         std::vector<float> xkvb((size_t)hp.n_text_layer * 2 * d, 0.0f);
@@ -350,6 +397,15 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
             D.ln2_w = put_f32(p + "mlp_ln.weight", d); D.ln2_b = put_f32(p + "mlp_ln.bias", d);
             D.fc1 = put_f16(p + "mlp.0.weight", 4 * dd); D.b1 = put_f32(p + "mlp.0.bias", 4 * (size_t)d);
             D.fc2 = put_f16(p + "mlp.2.weight", 4 * dd); D.b2 = put_f32(p + "mlp.2.bias", d);
+            if (keep_quant && !missing) {       // block-quantised files: the decoder's matrices stay resident as blocks too (few-row decode reads those)
+                auto tr = [&](const std::string &name) -> const TensorRef * { auto it = T.find(name); return it == T.end() ? nullptr : &it->second; };
+                D.q_wqkv = U.put_quant({tr(p + "attn.query.weight"), tr(p + "attn.key.weight"), tr(p + "attn.value.weight")});
+                D.q_wo = U.put_quant({tr(p + "attn.out.weight")});
+                D.q_xq = U.put_quant({tr(p + "cross_attn.query.weight")});
+                D.q_xo = U.put_quant({tr(p + "cross_attn.out.weight")});
+                D.q_fc1 = U.put_quant({tr(p + "mlp.0.weight")});
+                D.q_fc2 = U.put_quant({tr(p + "mlp.2.weight")});
+            }
             if (xkv) {
                 f16_into(p + "cross_attn.key.weight", dd, xkv + (size_t)(2 * i) * dd);
                 f16_into(p + "cross_attn.value.weight", dd, xkv + (size_t)(2 * i + 1) * dd);

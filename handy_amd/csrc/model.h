@@ -30,6 +30,7 @@ struct EncLayer {
 struct DecLayer {
     float *ln1_w, *ln1_b, *bqkv, *bo, *lnx_w, *lnx_b, *bxq, *bxo, *ln2_w, *ln2_b, *b1, *b2;
     f16 *wqkv, *wo, *xq, *xo, *fc1, *fc2;
+    QuantW q_wqkv, q_wo, q_xq, q_xo, q_fc1, q_fc2;      // the same matrices as the file's blocks (ttype 0: the file holds them as f16 / f32)
 };
 
 struct Model {
@@ -57,6 +58,10 @@ struct Model {
 // Parses `data` (a whole ggml file image) and uploads it to `device`. Returns nullptr (after logging) on any
 // malformed, truncated or unsupported input.
 Model *load_model(const uint8_t *data, size_t size, int device);
+
+// process-wide switch read by load_model (see model.cpp)
+void set_quant_resident(bool on);
+bool quant_resident();
 
 int lang_id_from_str(const char *s);
 const char *lang_str(int id);

@@ -95,6 +95,7 @@ WHISPER_API int wmi_debug_gemm_gelu(int M, int N, int K, const float *A, const f
 /* The loader's device-side expansion of ggml block-quantised tensors (types 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0; 32 weights a
  * block) on host buffers: blocks -> out[n_blocks * 32] as fp16 bit patterns. */
 WHISPER_API int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_blocks, unsigned short *out);
+WHISPER_API int wmi_debug_quant_rows(int ggml_type, const void *blocks, int N, int K, const unsigned short *a_f16, int rows, float *out_blocks, float *out_f16);   /* test hook: few-row GEMM on blocks vs on their fp16 expansion */
 
 #ifdef WMI_HARNESS
 /* Benchmark harness (libwhisper_mi355_harness.so, built from the same sources with -DWMI_HARNESS; the product library does not
@@ -117,6 +118,15 @@ WHISPER_API void wmi_reset_kernel_stats(struct whisper_state *state);
 
 /* Host-side clocks accumulated by the state, ms: [0] log-mel phase, [1] encoder launches, [2] decoder passes,
  * [3] of which building + launching, [4] of which waiting for the stream; [5] number of decoder passes. */
+/* Block-quantised model files (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0: the catalogue formats of
+ * /root/reference/src-tauri/src/managers/model.rs:97,135 among them) can keep their decoder weight matrices resident as the file's
+ * own blocks next to the fp16 copies; decode passes of at most 16 rows (one clip, its beams) then read the blocks and expand them in
+ * registers to the fp16 values the load-time expansion writes -- same results bit for bit, a third to a half of the weight bytes
+ * per token. wmi_set_quant_resident(1) before whisper_init_* (or WMI_QUANT_RESIDENT=1) turns the resident copies on for models
+ * loaded afterwards; it is off by default because those passes are bound by launch latency, not bytes, and the expansion costs
+ * more than it saves today. wmi_set_quant_decode(state, 0) makes a state read the fp16 copies although blocks are resident. */
+WHISPER_API void wmi_set_quant_resident(int on);
+WHISPER_API int wmi_set_quant_decode(struct whisper_state *state, int on);
 WHISPER_API int wmi_get_host_timings(struct whisper_state *state, double *out /* [6] */);
 
 WHISPER_API const char *wmi_version(void);

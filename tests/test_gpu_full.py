@@ -484,6 +484,49 @@ def test_quantised_files_load_and_match(wr, oracle, model_path):
         st.free(); ctx.free(); ost.close(); om.close()
 
 
+@pytest.mark.parametrize("arch", ["micro.en", "mini", "mini768"])
+def test_quantised_resident_decode_is_bit_identical(wr, oracle, model_path, arch):
+    """Block-quantised files keep the decoder's matrices resident as blocks; decode passes of at most 16 rows expand them in
+    registers instead of reading the fp16 copies. The expansion is the load-time one value for value, so logits and
+    transcripts are the same bits either way -- every block format, widths with and without split K, one row and a
+    short prompt -- and both agree with the oracle (which expands the file's blocks on the host)."""
+    pcm = synth_pcm(8, 9 * 16000)
+    rng = np.random.default_rng(5)
+    wr.load_library().wmi_set_quant_resident(1)           # (off by default: see include/wmi.h)
+    for ftype in (3, 8, 7, 2, 9):                         # Q4_1, Q5_0, Q8_0, Q4_0, Q5_1
+        path = model_path(arch, ftype=ftype, decisive=4.0)
+        om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+        ctx = wr.WhisperContext(path); st = ctx.create_state()
+        ost.pcm_to_mel(pcm); st.pcm_to_mel(pcm)
+        ost.encode(0); st.encode(0)
+        toks = [om.special("sot")] + [int(t) for t in rng.integers(0, 50000, size=11)]
+        lref = ost.decode(toks, 0, 0, logits_all=True)
+        got = {}
+        for on in (True, False):
+            st.set_quant_decode(on)
+            a = st.decode_logits_all(toks, 0)              # 12 rows in one pass
+            b = np.concatenate([st.decode_logits_all(toks[:5], 0)] + [st.decode([t], 5 + i)[None] for i, t in enumerate(toks[5:])])   # 5 rows, then one at a time
+            assert np.array_equal(a[:5], b[:5]) and np.array_equal(a[5:], b[5:, : a.shape[1]]), (arch, ftype, on)
+            got[on] = a
+        assert np.array_equal(got[True], got[False]), (arch, ftype, float(np.abs(got[True] - got[False]).max()))
+        err, scale = float(np.abs(got[True] - lref).max()), float(np.abs(lref).max())
+        print(arch, "ftype", ftype, "logits max abs err vs oracle", err, "max |ref|", scale)
+        assert err <= 1.5e-3 * max(1.0, scale), (arch, ftype, err, scale)      # observed 1.2e-2 at max |ref| 26 (decisive weights): 5e-4 of the range; three times that
+        st.free(); ost.close(); om.close()
+        # and whisper_full on one clip: same tokens and times with the blocks as with the fp16 copies
+        fp = wr.FullParams(wr.SamplingStrategy.BeamSearch(3, -1.0)); fp.set_language("en")
+        out = {}
+        for on in (True, False):
+            bs = ctx.create_batch_state(1, 3, 1)
+            bs.set_quant_decode(on)
+            bs.full_batch(fp, [pcm])
+            out[on] = [(g.t0, g.t1, tuple(g.tokens)) for g in bs.batch_segments(0)]
+            bs.free()
+        assert out[True] == out[False] and len(out[True]) > 0, (arch, ftype)
+        ctx.free()
+    wr.load_library().wmi_set_quant_resident(0)
+
+
 def test_bad_model_files_fail_cleanly(wr, model_path, tmp_path):
     good = open(model_path("micro.en"), "rb").read()
     for name, data in (("trunc.bin", good[: len(good) // 2]), ("magic.bin", b"\0" * 4096), ("hdr.bin", good[:40])):

@@ -71,6 +71,43 @@ def test_gelu_epilogue_over_every_f16_input(wr, M):
 
 
 @pytest.mark.parametrize("name", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0"])
+def test_few_row_gemm_on_blocks_equals_gemm_on_their_expansion(wr, name):
+    """The few-row decoder GEMM reading a weight matrix as ggml blocks (expanded in registers) against the same kernel reading
+    the load-time fp16 expansion of those blocks: identical fp32 results, bit for bit, for quantised data and for arbitrary
+    block bytes (every nibble, fifth-bit and sign pattern), with K split into slices (K = 1280, 3072) and unsplit (K = 64),
+    1 and 13 rows; and both equal A W^T computed in float64 from the expansion, to fp32 accumulation accuracy."""
+    import ctypes as C
+    from handy_amd import ggml_file as gf
+    tt = getattr(gf, "T_" + name)
+    L = wr.load_library()
+    L.wmi_debug_quant_rows.restype = C.c_int
+    L.wmi_debug_quant_rows.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(100 + tt)
+    bb = gf.TTYPE_BLOCK_BYTES[tt]
+    for (N, K, rows) in ((48, 64, 1), (128, 1280, 13), (64, 3072, 1), (32, 384, 16)):
+        n_blocks = N * K // 32
+        w = (rng.standard_normal(n_blocks * 32) * 0.05).astype(np.float32)
+        raws = [gf.quantize(w, tt)]
+        noise = rng.integers(0, 256, (n_blocks, bb), dtype=np.uint8)
+        scale = (rng.standard_normal((n_blocks, 2)) * 0.1).astype(np.float16)
+        noise[:, 0:2] = scale[:, 0:1].view(np.uint8)
+        if name in ("Q4_1", "Q5_1"):
+            noise[:, 2:4] = scale[:, 1:2].view(np.uint8)
+        raws.append(noise.tobytes())
+        a = (rng.standard_normal((rows, K)) * 0.5).astype(np.float16)
+        for raw in raws:
+            buf = np.frombuffer(raw, np.uint8)
+            yq = np.empty((rows, N), np.float32); yf = np.empty((rows, N), np.float32)
+            assert L.wmi_debug_quant_rows(tt, buf.ctypes.data_as(C.c_void_p), N, K, a.ctypes.data_as(C.c_void_p), rows,
+                                          yq.ctypes.data_as(C.c_void_p), yf.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(yq.view(np.uint32) & 0x7FFFFFFF | (yq != 0) * (yq.view(np.uint32) & 0x80000000), yf.view(np.uint32) & 0x7FFFFFFF | (yf != 0) * (yf.view(np.uint32) & 0x80000000)), \
+                (name, N, K, rows, float(np.abs(yq - yf).max()))           # same bits (the sign of an exact zero aside)
+            wref = gf.dequantize(raw, tt, n_blocks * 32).astype(np.float16).astype(np.float64).reshape(N, K)
+            ref = a.astype(np.float64) @ wref.T
+            assert np.abs(yf - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (name, N, K, float(np.abs(yf - ref).max()))
+
+
+@pytest.mark.parametrize("name", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0"])
 def test_block_expansion_is_bit_exact(wr, name):
     """The loader's device-side expansion of ggml block formats against the numpy expansion of the same bytes: identical
     fp16 bit patterns, on quantised data and on arbitrary block bytes (every nibble, high bit and sign pattern)."""
