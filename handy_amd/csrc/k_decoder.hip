@@ -128,7 +128,7 @@ bool dec_self_attention(const f16 *q, const f16 *kc, const f16 *vc, const int *b
 // a workgroup takes a group of up to NQ such rows (consecutive in the pass; the host passes {first row, count})
 // and applies every key it loads to all of them, so the cache is streamed once per group, not once per row.
 template <int NQ>
-__global__ __launch_bounds__(256) void dec_cross_attention_kernel(const f16 *__restrict__ qb, const f16 *__restrict__ ckv, const DecRow *__restrict__ rows,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void dec_cross_attention_kernel(const f16 *__restrict__ qb, const f16 *__restrict__ ckv, const DecRow *__restrict__ rows,
                                                                   const int2 *__restrict__ groups, int d, int H, int T, int Tp, int n_layer, int layer, f16 *__restrict__ att) {
     __shared__ float red[4][8][10];
     const int head = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 3, e8 = lane & 7;
@@ -147,6 +147,15 @@ __global__ __launch_bounds__(256) void dec_cross_attention_kernel(const f16 *__r
     }
     int j = wave * 8 + g;
     if (NQ == 1) {
+        // eight independent key rows (16 x 16-byte loads per lane) in flight per iteration: with one clip the launch is 20
+        // workgroups of 384 KB each, and what a wave has in flight bounds its rate; the keys are still applied in order
+        for (; j + 224 < T; j += 256) {
+            f16x8 k[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { k[u] = __builtin_nontemporal_load((const f16x8 *)(kp + (long)(j + 32 * u) * 64)); v[u] = __builtin_nontemporal_load((const f16x8 *)(vp + (long)(j + 32 * u) * 64)); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) attn_step(s[0], q[0], k[u], v[u]);
+        }
         for (; j + 96 < T; j += 128) {     // four independent key rows (8 x 16-byte loads per lane) in flight per iteration
             f16x8 k[4], v[4];
 #pragma unroll
