@@ -46,10 +46,6 @@ void PinnedBuf::release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 // epilogue, which accumulates K slice by slice in the same order -- the two paths give the same bits, so the threshold is
 // a pure speed choice (WMI_SPLIT_ROWS overrides it for experiments): at 320 rows the partial sums of ten slices are five
 // times the weight bytes.
-static int spin_wait_us() {            // WMI_SPIN_US: how long a decoder pass polls for its results before it blocks (0: block at once)
-    static const int v = [] { const char *e = getenv("WMI_SPIN_US"); return e ? atoi(e) : 2000; }();
-    return v;
-}
 static bool few_rows_path() {          // WMI_FEW_ROWS=0 turns the few-row kernels off (A/B measurements)
     static const bool v = [] { const char *e = getenv("WMI_FEW_ROWS"); return !e || atoi(e) != 0; }();
     return v;
@@ -564,14 +560,6 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
         if (any_probs) WMI_HIP_OK(hipMemcpyAsync(probs_host_.p, probs_.p, sizeof(float) * (size_t)L * V_, hipMemcpyDeviceToHost, stream_));
     }
     const double t_launched = now_ms();
-    // The end of a pass is on every token's critical path: poll the stream for a while (a blocking wait wakes up tens of
-    // microseconds after the GPU is done, a tenth of a one-clip pass) before falling back to the blocking wait.
-    if (spin_wait_us() > 0) {
-        const double t_end = t_launched + spin_wait_us() * 1e-3;
-        hipError_t q;
-        while ((q = hipStreamQuery(stream_)) == hipErrorNotReady && now_ms() < t_end) {}
-        if (q != hipSuccess && q != hipErrorNotReady) { log_msg(2, "decoder pass: %s\n", hipGetErrorString(q)); return false; }
-    }
     WMI_HIP_OK(hipStreamSynchronize(stream_));
     t_dec_launch_ms += t_launched - t_pass0; t_dec_wait_ms += now_ms() - t_launched; n_passes++;
     n_decode += R;

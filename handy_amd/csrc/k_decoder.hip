@@ -219,7 +219,8 @@ bool cross_v_transpose(const f16 *ckv, const int *slots, int n_slots, f16 *vt, i
 //   softmax                  running maximum per row kept equal in the 4 lanes that share the row (two shuffles per
 //                            tile), because all of them feed one accumulator
 //   O^T[dim][row] += V^T P^T P^T goes from the score registers straight into the B operand; V^T comes from the transposed
-//                            copy in the key order that layout implies (two 8-byte loads per lane and 16 dims)
+//                            copy; the K rows of a tile are taken in the order that makes a lane's 8 scores 8 consecutive
+//                            keys, so its V^T operand is one 16-byte load per 16 dims
 // Every K and V byte of the head is read once per group; the four waves' partial results meet in LDS. (No non-temporal
 // hint on these loads, unlike the row-per-workgroup kernel: a 128-byte line here is consumed by several load
 // instructions and has to stay cached between them -- with the hint the kernel drops from 4.7 to 3.6 TB/s.)
@@ -242,17 +243,18 @@ __global__ __launch_bounds__(256) void dec_cross_attention_mq_kernel(const f16 *
     for (int i = 0; i < 4; i++) o[i] = f32x4{0, 0, 0, 0};
     float m_run = -INFINITY, l_run = 0.0f;
     const int n_tiles = (T + 31) / 32;
-    struct Frags { f16x8 k[2][2]; f16x4 v[4][2]; };
+    // Key order inside a 32-key tile: row i of score tile u is key (i >> 2) * 8 + u * 4 + (i & 3), so that the 8 scores a lane
+    // ends up with (rows 4g .. 4g+3 of both tiles) are the 8 consecutive keys 8g .. 8g+7 -- its V^T operand is then one
+    // 16-byte load per 16 dims instead of two 8-byte ones.
+    struct Frags { f16x8 k[2][2]; f16x8 v[4]; };
     auto load_tile = [&](Frags &f, int t) {
         const int key0 = t * 32;
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) f.k[u][ks] = *(const f16x8 *)(kp + (long)(key0 + u * 16 + n) * 64 + ks * 32 + g * 8);
+            for (int ks = 0; ks < 2; ks++) f.k[u][ks] = *(const f16x8 *)(kp + (long)(key0 + (n >> 2) * 8 + u * 4 + (n & 3)) * 64 + ks * 32 + g * 8);
 #pragma unroll
-        for (int db = 0; db < 4; db++)
-#pragma unroll
-            for (int u = 0; u < 2; u++) f.v[db][u] = *(const f16x4 *)(vp + (long)(db * 16 + n) * Tp + key0 + u * 16 + g * 4);
+        for (int db = 0; db < 4; db++) f.v[db] = *(const f16x8 *)(vp + (long)(db * 16 + n) * Tp + key0 + g * 8);
     };
     auto compute_tile = [&](const Frags &f, int t) {
         f32x4 s[2];
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void dec_cross_attention_mq_kernel(const f16 *
         for (int u = 0; u < 2; u++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                if (t * 32 + u * 16 + g * 4 + r >= T) s[u][r] = -INFINITY;
+                if (t * 32 + g * 8 + u * 4 + r >= T) s[u][r] = -INFINITY;
                 mx = fmaxf(mx, s[u][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -283,8 +285,7 @@ __global__ __launch_bounds__(256) void dec_cross_attention_mq_kernel(const f16 *
 #pragma unroll
         for (int db = 0; db < 4; db++) {
             o[db] *= alpha;
-            const f16x8 va = {f.v[db][0][0], f.v[db][0][1], f.v[db][0][2], f.v[db][0][3], f.v[db][1][0], f.v[db][1][1], f.v[db][1][2], f.v[db][1][3]};
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pf, o[db], 0, 0, 0);
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.v[db], pf, o[db], 0, 0, 0);
         }
     };
     // two register sets: the next tile of this wave is in flight while the current one is multiplied

@@ -26,6 +26,6 @@ for arch in sys.argv[1:] or ["tiny.en", "large-v3-turbo"]:
     h1 = st.host_timings()
     d = {k: (h1[k] - h0[k]) / 5 for k in h0}
     out[arch] = {"wall_ms": sorted(walls)[2], "per_call": d, "us_per_pass": 1e3 * d["decode_ms"] / max(1.0, d["passes"]),
-                 "spin_us": os.environ.get("WMI_SPIN_US", "default"), "few_rows": os.environ.get("WMI_FEW_ROWS", "default"), "ftype": ftype, "quant_decode": os.environ.get("WMI_PROBE_QUANT", "1")}
+                 "few_rows": os.environ.get("WMI_FEW_ROWS", "default"), "ftype": ftype, "quant_decode": os.environ.get("WMI_PROBE_QUANT", "1")}
     print(arch, json.dumps(out[arch]), flush=True)
     st.free(); ctx.free()
