@@ -376,6 +376,11 @@ int wmi_get_cross_kv(struct whisper_state *s, int layer, float *k, float *v) {
     Engine *e = ENG(s); return e && k && v ? e->get_cross_kv(layer, k, v) : -1;
     WMI_CATCH(-1)
 }
+int wmi_set_decoder_lanes(struct whisper_state *s, int n) {
+    Engine *e = ENG(s); if (!e) return -1;
+    e->set_decoder_lanes(n);
+    return 0;
+}
 void wmi_set_quant_resident(int on) { wmi::set_quant_resident(on != 0); }
 int wmi_set_quant_decode(struct whisper_state *s, int on) {
     Engine *e = ENG(s); if (!e) return -1;

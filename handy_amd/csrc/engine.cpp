@@ -66,6 +66,9 @@ Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
     if (hipSetDevice(m->device) != hipSuccess) return;
     if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return;
     for (int l = 0; l < kEncLanes; l++) if (hipStreamCreateWithFlags(&enc_streams_[l], hipStreamNonBlocking) != hipSuccess) return;
+    if (hipStreamCreateWithFlags(&lane_stream_, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&lane_fork_, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&lane_join_, hipEventDisableTiming) != hipSuccess) return;
+    if (const char *e = getenv("WMI_DEC_LANES")) set_decoder_lanes(atoi(e));
     prof_stream_ = stream_;
     ok_ = alloc_workspaces();
 }
@@ -78,13 +81,16 @@ Engine::~Engine() {
         for (DevBuf *b : {&ews_[l].melT, &ews_[l].h1, &ews_[l].x, &ews_[l].xn, &ews_[l].q, &ews_[l].k, &ews_[l].vt, &ews_[l].att, &ews_[l].hid, &ews_[l].enc16}) b->release();
     }
     for (DevBuf *b : {&pcm_, &mel_raw_, &mel_max_, &mel_utt_dev_, &mel_norm_tmp_, &enc32_,
-                      &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_, &sample_ws_, &splitk_ws_, &ckvt_})
+                      &win_dev_, &slots_dev_, &ckv_, &dx_, &dxn_, &dq_, &datt_, &dhid_, &dxl_, &logits_, &probs_, &kpool_, &vpool_, &meta_dev_, &out_dev_, &sample_ws_, &splitk_ws_, &lane_ws_, &ckvt_})
         b->release();
     meta_host_.release(); out_host_.release(); probs_host_.release(); win_host_.release(); slots_host_.release();
     for (hipEvent_t e : enc_events_) (void)hipEventDestroy(e);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (stream_) (void)hipStreamDestroy(stream_);
     for (int l = 0; l < kEncLanes; l++) if (enc_streams_[l]) (void)hipStreamDestroy(enc_streams_[l]);
+    if (lane_stream_) { (void)hipStreamSynchronize(lane_stream_); (void)hipStreamDestroy(lane_stream_); }
+    if (lane_fork_) (void)hipEventDestroy(lane_fork_);
+    if (lane_join_) (void)hipEventDestroy(lane_join_);
 }
 
 bool Engine::alloc_workspaces() {
@@ -162,7 +168,7 @@ bool Engine::ensure_rows(int rows) {
     size_t ws_bytes = 4096;
     for (const auto &nk : {std::pair<int, int>{3 * d_, d_}, {d_, d_}, {4 * d_, d_}, {d_, 4 * d_}})
         ws_bytes = std::max(ws_bytes, gemm_splitk_workspace_bytes(ws_rows, nk.first, nk.second));
-    ok = ok && splitk_ws_.ensure(ws_bytes, false);
+    ok = ok && splitk_ws_.ensure(ws_bytes, false) && lane_ws_.ensure(ws_bytes, false);
     if (ok) rows_cap_ = (int)R;
     return ok;
 }
@@ -447,87 +453,126 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     const int2 *d_grp = max_group > 1 ? (const int2 *)(db + o_grp) : nullptr;
     f16 *kp = kpool_.as<f16>(), *vp = vpool_.as<f16>();
     if (C) PROF(WMI_K_DEC_OTHER, 0, copy_pages(kp, vp, layer_stride_, Ld_, d_copy, C, H_, stream_));
-    PROF(WMI_K_DEC_OTHER, (double)R * d * 6, dec_embed(model->d_te, model->d_pe, d_rows, R, d, dx_.as<float>(), stream_));
-    const double ln_bytes = (double)R * d * 6, w1 = 2.0 * d * d;           // bytes of one d x d fp16 weight
-    // Skinny GEMMs go through split-K (partials in splitk_ws_, summed by the consumer that also applies the
-    // epilogue and, for the residual GEMMs, the LayerNorm that follows); wide passes use the fused epilogues.
-    float *ws = splitk_ws_.as<float>();
-    const bool may_split = (size_t)R <= split_max_rows();
-    const int s_qkv = may_split ? gemm_pick_splits(3 * d, d) : 1, s_dd = may_split ? gemm_pick_splits(d, d) : 1,
-              s_fc1 = may_split ? gemm_pick_splits(4 * d, d) : 1, s_fc2 = may_split ? gemm_pick_splits(d, 4 * d) : 1;
+    const double w1 = 2.0 * d * d;           // bytes of one d x d fp16 weight
     prof_stream_ = stream_;
-    const bool fused_ln = s_dd > 1 && s_fc2 > 1;      // x += ... and the next LayerNorm in one kernel
-    auto residual_ln = [&](const f16 *a, int K, const f16 *Wt, const float *bias, int splits, const float *lw, const float *lb, f16 *out, const int *gather, int n_out) -> bool {
-        PROF(WMI_K_DEC_GEMM, 2.0 * d * K, gemm_splitk(a, K, Wt, K, R, d, K, splits, ws, splitk_ws_.cap, stream_));
-        PROF(WMI_K_DEC_OTHER, ln_bytes, splitk_residual_ln(dx_.as<float>(), ws, splits, bias, lw, lb, out, R, d, gather, n_out, stream_));
+    // The decoder layers over rows [r0, r0 + Rn) of the pass (cross-attention row groups [g0, g0 + NGn)) on stream `st`, partial sums
+    // in `ws`. Three GEMM paths by row count, all with the same bits: at most 16 rows -- one launch per projection (LayerNorm in its
+    // prologue, bias / residual / GELU in its epilogue), 8 launches per layer; up to split_max_rows() -- split-K with consumers that
+    // also apply the epilogue and, for the residual GEMMs, the LayerNorm that follows; more -- fused-epilogue tiles + LayerNorm.
+    // Leaves the residual stream of its rows in dx_; the final LayerNorm of the logit rows follows on the pass's stream.
+    auto run_layers = [&](int r0, int Rn, int g0, int NGn, int max_grp, hipStream_t st, float *ws, size_t ws_cap) -> bool {
+        float *x = dx_.as<float>() + (size_t)r0 * d;
+        f16 *xn = dxn_.as<f16>() + (size_t)r0 * d, *q = dq_.as<f16>() + (size_t)r0 * d, *att = datt_.as<f16>() + (size_t)r0 * d, *hid = dhid_.as<f16>() + (size_t)r0 * 4 * d;
+        const DecRow *rw = d_rows + r0;
+        const double ln_bytes = (double)Rn * d * 6;
+        PROF(WMI_K_DEC_OTHER, (double)Rn * d * 6, dec_embed(model->d_te, model->d_pe, rw, Rn, d, x, st));
+        const bool may_split = (size_t)Rn <= split_max_rows();
+        const int s_qkv = may_split ? gemm_pick_splits(3 * d, d) : 1, s_dd = may_split ? gemm_pick_splits(d, d) : 1,
+                  s_fc1 = may_split ? gemm_pick_splits(4 * d, d) : 1, s_fc2 = may_split ? gemm_pick_splits(d, 4 * d) : 1;
+        const bool fused_ln = s_dd > 1 && s_fc2 > 1;      // x += ... and the next LayerNorm in one kernel
+        auto residual_ln = [&](const f16 *a, int K, const f16 *Wt, const float *bias, int splits, const float *lw, const float *lb) -> bool {
+            PROF(WMI_K_DEC_GEMM, 2.0 * d * K, gemm_splitk(a, K, Wt, K, Rn, d, K, splits, ws, ws_cap, st));
+            PROF(WMI_K_DEC_OTHER, ln_bytes, splitk_residual_ln(x, ws, splits, bias, lw, lb, xn, Rn, d, nullptr, Rn, st));
+            return true;
+        };
+        auto cross = [&](int l) -> bool {
+            if (mq && max_grp > 1)      // the group lists hold pass-wide row numbers: buffers from row 0
+                PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp + g0, NGn, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), st));
+            else if (max_grp > 1)
+                PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp + g0, NGn, max_grp, Rn, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), st));
+            else
+                PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention(q, ckv_.as<f16>(), rw, nullptr, NGn, 1, Rn, d, H_, T, Tp_full_, Ld_, l, att, st));
+            return true;
+        };
+        const bool few_rows = few_rows_path() && gemm_rows_ok(Rn, d, d, true) && gemm_rows_ok(Rn, d, 4 * d, false);
+        if (fused_ln && !few_rows) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, model->dec[0].ln1_w, model->dec[0].ln1_b, xn, nullptr, Rn, d, nullptr, st));
+        for (int l = 0; l < Ld_; l++) {
+            const DecLayer &D = model->dec[l];
+            f16 *kl = kp + l * layer_stride_, *vl = vp + l * layer_stride_;
+            if (few_rows) {
+                auto qw = [&](const QuantW &qq) -> const QuantW * { return quant_decode && qq.ttype ? &qq : nullptr; };
+                PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_rows_ln_dec_qkv(x, D.ln1_w, D.ln1_b, D.wqkv, Rn, d, H_, q, kl, vl, D.bqkv, rw, st, qw(D.q_wqkv)));
+                PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(q, kl, vl, d_bt, rw, Rn, d, H_, att, st));
+                PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(att, d, D.wo, Rn, d, d, x, d, D.bo, st, qw(D.q_wo)));
+                PROF(WMI_K_DEC_GEMM, w1, gemm_rows_ln_f16(x, D.lnx_w, D.lnx_b, D.xq, Rn, d, d, q, d, D.bxq, 0, 0.125f, st, qw(D.q_xq)));
+                if (!cross(l)) return false;
+                PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(att, d, D.xo, Rn, d, d, x, d, D.bxo, st, qw(D.q_xo)));
+                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_ln_f16(x, D.ln2_w, D.ln2_b, D.fc1, Rn, 4 * d, d, hid, 4 * d, D.b1, 1, 1.0f, st, qw(D.q_fc1)));
+                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_residual(hid, 4 * d, D.fc2, Rn, d, 4 * d, x, d, D.b2, st, qw(D.q_fc2)));
+                continue;
+            }
+            if (!fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.ln1_w, D.ln1_b, xn, nullptr, Rn, d, nullptr, st));
+            if (s_qkv > 1) {
+                PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_splitk(xn, d, D.wqkv, d, Rn, 3 * d, d, s_qkv, ws, ws_cap, st));
+                PROF(WMI_K_DEC_OTHER, (double)Rn * 3 * d * 2, splitk_dec_qkv(ws, s_qkv, D.bqkv, rw, Rn, d, H_, q, kl, vl, st));
+            } else {
+                PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_dec_qkv(xn, D.wqkv, Rn, d, H_, q, kl, vl, D.bqkv, rw, st));
+            }
+            PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(q, kl, vl, d_bt, rw, Rn, d, H_, att, st));
+            if (fused_ln) { if (!residual_ln(att, d, D.wo, D.bo, s_dd, D.lnx_w, D.lnx_b)) return false; }
+            else {
+                PROF(WMI_K_DEC_GEMM, w1, gemm_residual(att, d, D.wo, d, Rn, d, d, x, d, D.bo, st, true));
+                PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.lnx_w, D.lnx_b, xn, nullptr, Rn, d, nullptr, st));
+            }
+            if (s_dd > 1) {
+                PROF(WMI_K_DEC_GEMM, w1, gemm_splitk(xn, d, D.xq, d, Rn, d, d, s_dd, ws, ws_cap, st));
+                PROF(WMI_K_DEC_OTHER, (double)Rn * d * 2, splitk_f16(ws, s_dd, D.bxq, 0, 0.125f, q, Rn, d, st));
+            } else {
+                PROF(WMI_K_DEC_GEMM, w1, gemm_f16(xn, d, D.xq, d, Rn, d, d, q, d, D.bxq, 0, 0.125f, st, true));
+            }
+            if (!cross(l)) return false;
+            if (fused_ln) { if (!residual_ln(att, d, D.xo, D.bxo, s_dd, D.ln2_w, D.ln2_b)) return false; }
+            else {
+                PROF(WMI_K_DEC_GEMM, w1, gemm_residual(att, d, D.xo, d, Rn, d, d, x, d, D.bxo, st, true));
+                PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.ln2_w, D.ln2_b, xn, nullptr, Rn, d, nullptr, st));
+            }
+            if (s_fc1 > 1) {
+                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_splitk(xn, d, D.fc1, d, Rn, 4 * d, d, s_fc1, ws, ws_cap, st));
+                PROF(WMI_K_DEC_OTHER, (double)Rn * 4 * d * 2, splitk_f16(ws, s_fc1, D.b1, 1, 1.0f, hid, Rn, 4 * d, st));
+            } else {
+                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(xn, d, D.fc1, d, Rn, 4 * d, d, hid, 4 * d, D.b1, 1, 1.0f, st, true));
+            }
+            if (fused_ln) {
+                // (after the last layer the LayerNorm this writes is not used: the logit rows get theirs below)
+                const float *lw = l + 1 < Ld_ ? model->dec[l + 1].ln1_w : model->d_ln_w, *lb = l + 1 < Ld_ ? model->dec[l + 1].ln1_b : model->d_ln_b;
+                if (!residual_ln(hid, 4 * d, D.fc2, D.b2, s_fc2, lw, lb)) return false;
+            } else {
+                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_residual(hid, 4 * d, D.fc2, 4 * d, Rn, d, 4 * d, x, d, D.b2, st, true));
+            }
+        }
         return true;
     };
-    // Passes of at most 16 rows: one launch per projection (LayerNorm in its prologue, bias / residual / GELU in its epilogue),
-    // 8 launches per layer instead of 12-14; same bits as the other two paths.
-    const bool few_rows = few_rows_path() && gemm_rows_ok(R, d, d, true) && gemm_rows_ok(R, d, 4 * d, false);
-    if (fused_ln && !few_rows) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), model->dec[0].ln1_w, model->dec[0].ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
-    for (int l = 0; l < Ld_; l++) {
-        const DecLayer &D = model->dec[l];
-        f16 *kl = kp + l * layer_stride_, *vl = vp + l * layer_stride_;
-        if (few_rows) {
-            float *x = dx_.as<float>();
-            auto qw = [&](const QuantW &q) -> const QuantW * { return quant_decode && q.ttype ? &q : nullptr; };
-            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_rows_ln_dec_qkv(x, D.ln1_w, D.ln1_b, D.wqkv, R, d, H_, dq_.as<f16>(), kl, vl, D.bqkv, d_rows, stream_, qw(D.q_wqkv)));
-            PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(dq_.as<f16>(), kl, vl, d_bt, d_rows, R, d, H_, datt_.as<f16>(), stream_));
-            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(datt_.as<f16>(), d, D.wo, R, d, d, x, d, D.bo, stream_, qw(D.q_wo)));
-            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_ln_f16(x, D.lnx_w, D.lnx_b, D.xq, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_, qw(D.q_xq)));
-            if (mq && max_group > 1)
-                PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp, NG, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
-            else
-                PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp, NG, max_group, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
-            PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(datt_.as<f16>(), d, D.xo, R, d, d, x, d, D.bxo, stream_, qw(D.q_xo)));
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_ln_f16(x, D.ln2_w, D.ln2_b, D.fc1, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_, qw(D.q_fc1)));
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_residual(dhid_.as<f16>(), 4 * d, D.fc2, R, d, 4 * d, x, d, D.b2, stream_, qw(D.q_fc2)));
-            continue;
+    // Row lanes: the kernels of a pass of a few hundred rows are chains of dependent 5-30 us launches that leave most of the chip
+    // idle (100-400 workgroups, each bound by its own latency chain). Two halves of the rows on two streams run two such chains
+    // side by side; since no path's arithmetic depends on the rows that share its launches, the halves give the bits the whole
+    // pass would. The pass's stream forks after the metadata upload and joins before the logits.
+    const bool prof_dec = profiling && (profile_mask & ((1u << WMI_K_DEC_GEMM) | (1u << WMI_K_DEC_OTHER) | (1u << WMI_K_DEC_CROSS_ATTN)));
+    int cut_row = 0, cut_grp = 0;
+    if (dec_lanes_ > 1 && !prof_dec && R >= 2 * kDecLaneMinRows && lane_stream_ && lane_ws_.p) {
+        // cut at the cross-attention group boundary nearest to the middle (rows of one utterance stay in one lane)
+        int best = -1;
+        for (int gi = 1; gi < NG; gi++) {
+            const int r = xgroups_[gi].x;
+            if (xgroups_[gi - 1].x + xgroups_[gi - 1].y == r && rows[r].utt != rows[r - 1].utt && (best < 0 || abs(r - R / 2) < abs(xgroups_[best].x - R / 2))) best = gi;
         }
-        if (!fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln1_w, D.ln1_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
-        if (s_qkv > 1) {
-            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_splitk(dxn_.as<f16>(), d, D.wqkv, d, R, 3 * d, d, s_qkv, ws, splitk_ws_.cap, stream_));
-            PROF(WMI_K_DEC_OTHER, (double)R * 3 * d * 2, splitk_dec_qkv(ws, s_qkv, D.bqkv, d_rows, R, d, H_, dq_.as<f16>(), kl, vl, stream_));
-        } else {
-            PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_dec_qkv(dxn_.as<f16>(), D.wqkv, R, d, H_, dq_.as<f16>(), kl, vl, D.bqkv, d_rows, stream_));
-        }
-        PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(dq_.as<f16>(), kl, vl, d_bt, d_rows, R, d, H_, datt_.as<f16>(), stream_));
-        if (fused_ln) { if (!residual_ln(datt_.as<f16>(), d, D.wo, D.bo, s_dd, D.lnx_w, D.lnx_b, dxn_.as<f16>(), nullptr, R)) return false; }
-        else {
-            PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.wo, d, R, d, d, dx_.as<float>(), d, D.bo, stream_, true));
-            PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.lnx_w, D.lnx_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
-        }
-        if (s_dd > 1) {
-            PROF(WMI_K_DEC_GEMM, w1, gemm_splitk(dxn_.as<f16>(), d, D.xq, d, R, d, d, s_dd, ws, splitk_ws_.cap, stream_));
-            PROF(WMI_K_DEC_OTHER, (double)R * d * 2, splitk_f16(ws, s_dd, D.bxq, 0, 0.125f, dq_.as<f16>(), R, d, stream_));
-        } else {
-            PROF(WMI_K_DEC_GEMM, w1, gemm_f16(dxn_.as<f16>(), d, D.xq, d, R, d, d, dq_.as<f16>(), d, D.bxq, 0, 0.125f, stream_, true));
-        }
-        if (mq && max_group > 1)
-            PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp, NG, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
-        else
-        PROF(WMI_K_DEC_CROSS_ATTN, (double)NG * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp, NG, max_group, R, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), stream_));
-        if (fused_ln) { if (!residual_ln(datt_.as<f16>(), d, D.xo, D.bxo, s_dd, D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R)) return false; }
-        else {
-            PROF(WMI_K_DEC_GEMM, w1, gemm_residual(datt_.as<f16>(), d, D.xo, d, R, d, d, dx_.as<float>(), d, D.bxo, stream_, true));
-            PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(dx_.as<float>(), D.ln2_w, D.ln2_b, dxn_.as<f16>(), nullptr, R, d, nullptr, stream_));
-        }
-        if (s_fc1 > 1) {
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_splitk(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, s_fc1, ws, splitk_ws_.cap, stream_));
-            PROF(WMI_K_DEC_OTHER, (double)R * 4 * d * 2, splitk_f16(ws, s_fc1, D.b1, 1, 1.0f, dhid_.as<f16>(), R, 4 * d, stream_));
-        } else {
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(dxn_.as<f16>(), d, D.fc1, d, R, 4 * d, d, dhid_.as<f16>(), 4 * d, D.b1, 1, 1.0f, stream_, true));
-        }
-        if (fused_ln) {
-            if (l + 1 < Ld_) { if (!residual_ln(dhid_.as<f16>(), 4 * d, D.fc2, D.b2, s_fc2, model->dec[l + 1].ln1_w, model->dec[l + 1].ln1_b, dxn_.as<f16>(), nullptr, R)) return false; }
-            else if (L > 0) { if (!residual_ln(dhid_.as<f16>(), 4 * d, D.fc2, D.b2, s_fc2, model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), d_gather, L)) return false; }
-        } else {
-            PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_residual(dhid_.as<f16>(), 4 * d, D.fc2, 4 * d, R, d, 4 * d, dx_.as<float>(), d, D.b2, stream_, true));
-        }
+        if (best > 0 && xgroups_[best].x >= kDecLaneMinRows && R - xgroups_[best].x >= kDecLaneMinRows) { cut_grp = best; cut_row = xgroups_[best].x; }
+    }
+    if (cut_row > 0) {
+        int mg0 = 1, mg1 = 1;
+        for (int gi = 0; gi < NG; gi++) (gi < cut_grp ? mg0 : mg1) = std::max(gi < cut_grp ? mg0 : mg1, xgroups_[gi].y);
+        WMI_HIP_OK(hipEventRecord(lane_fork_, stream_));
+        WMI_HIP_OK(hipStreamWaitEvent(lane_stream_, lane_fork_, 0));
+        const bool ok1 = run_layers(cut_row, R - cut_row, cut_grp, NG - cut_grp, mg1, lane_stream_, lane_ws_.as<float>(), lane_ws_.cap);
+        const bool ok0 = run_layers(0, cut_row, 0, cut_grp, mg0, stream_, splitk_ws_.as<float>(), splitk_ws_.cap);
+        // join even when a launch failed: nothing may still run on the lane when this pass returns
+        WMI_HIP_OK(hipEventRecord(lane_join_, lane_stream_));
+        WMI_HIP_OK(hipStreamWaitEvent(stream_, lane_join_, 0));
+        if (!ok0 || !ok1) { (void)hipStreamSynchronize(stream_); return false; }
+    } else {
+        if (!run_layers(0, R, 0, NG, max_group, stream_, splitk_ws_.as<float>(), splitk_ws_.cap)) return false;
     }
     if (L > 0) {
-        if (!fused_ln || few_rows) PROF(WMI_K_DEC_OTHER, (double)L * d * 6, layer_norm(dx_.as<float>(), model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), nullptr, L, d, d_gather, stream_));
+        PROF(WMI_K_DEC_OTHER, (double)L * d * 6, layer_norm(dx_.as<float>(), model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), nullptr, L, d, d_gather, stream_));
         PROF(WMI_K_DEC_GEMM, 2.0 * Vp_ * d + 4.0 * L * Vp_, gemm_f32(dxl_.as<f16>(), d, model->d_te, d, L, Vp_, d, logits_.as<float>(), Vp_, nullptr, stream_));
         if (logits_all_out) WMI_HIP_OK(hipMemcpy2DAsync(logits_all_out, sizeof(float) * V_, logits_.p, sizeof(float) * Vp_, sizeof(float) * V_, L, hipMemcpyDeviceToHost, stream_));
         if (want_raw_logits_host) WMI_HIP_OK(hipMemcpyAsync(logits_host_.data(), logits_.as<float>() + (size_t)(L - 1) * Vp_, sizeof(float) * V_, hipMemcpyDeviceToHost, stream_));

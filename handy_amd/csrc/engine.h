@@ -132,7 +132,8 @@ public:
 
     // profiling
     bool profiling = false;
-    bool quant_decode = true;           // few-row decode passes read the decoder weights as the file's blocks where the model holds them
+    bool quant_decode = true;
+    void set_decoder_lanes(int n) { dec_lanes_ = n < 1 ? 1 : (n > 2 ? 2 : n); }           // few-row decode passes read the decoder weights as the file's blocks where the model holds them
     unsigned profile_mask = ~0u;        // bit per wmi_kernel_class: which classes get event pairs while profiling is on
     wmi_kernel_stat stats[WMI_K_COUNT]{};
     void collect_stats();
@@ -163,6 +164,12 @@ private:
     static constexpr int kEncLanes = 2;
     EncWs ews_[kEncLanes];
     hipStream_t enc_streams_[kEncLanes] = {nullptr, nullptr};
+    // second row lane of a decoder pass (see decoder_pass): its stream, fork / join events and split-K workspace
+    static constexpr int kDecLaneMinRows = 16;
+    int dec_lanes_ = 1;
+    hipStream_t lane_stream_ = nullptr;
+    hipEvent_t lane_fork_ = nullptr, lane_join_ = nullptr;
+    DevBuf lane_ws_;
     int next_lane_ = 0;
     DevBuf enc32_, win_dev_, slots_dev_;
     PinnedBuf win_host_, slots_host_;    // per-chunk metadata: a ring, so that several chunks can be queued before the first one runs

@@ -124,7 +124,7 @@ whisper_full_get_token_data whisper_full_get_token_data_from_state whisper_full_
 wmi_init_state_batch wmi_full_batch wmi_batch_n_utts wmi_batch_n_segments wmi_batch_segment_t0 wmi_batch_segment_t1
 wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks wmi_batch_rc
 wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_pcm_to_mel_device_noalloc wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
-wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_debug_quant_rows wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_set_quant_decode wmi_set_quant_resident wmi_version
+wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_debug_quant_rows wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_set_quant_decode wmi_set_quant_resident wmi_set_decoder_lanes wmi_version
 """.split()
 
 _lib = None
@@ -211,6 +211,7 @@ def load_library(path: Optional[str] = None):
     L.wmi_get_host_timings.restype = ci; L.wmi_get_host_timings.argtypes = [vp, C.POINTER(C.c_double)]
     L.wmi_set_quant_decode.restype = ci; L.wmi_set_quant_decode.argtypes = [vp, ci]
     L.wmi_set_quant_resident.restype = None; L.wmi_set_quant_resident.argtypes = [ci]
+    L.wmi_set_decoder_lanes.restype = ci; L.wmi_set_decoder_lanes.argtypes = [vp, ci]
     if path is None:
         _lib = L
     return L
@@ -532,6 +533,9 @@ class WhisperState:
         for n in names: mask |= 1 << KERNEL_CLASSES.index(n)
         self.L.wmi_set_profiling_classes(self.h, mask)
     def reset_kernel_stats(self): self.L.wmi_reset_kernel_stats(self.h)
+    def set_decoder_lanes(self, n: int):
+        """Row lanes of a decoder pass (1 or 2 HIP streams)."""
+        if self.L.wmi_set_decoder_lanes(self.h, int(n)) != 0: raise WhisperError("GenericError", -1)
     def set_quant_decode(self, on: bool):
         """Few-row decode passes read block-quantised decoder weights as blocks (default) or their fp16 copies."""
         if self.L.wmi_set_quant_decode(self.h, 1 if on else 0) != 0: raise WhisperError("GenericError", -1)

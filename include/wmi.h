@@ -125,6 +125,11 @@ WHISPER_API void wmi_reset_kernel_stats(struct whisper_state *state);
  * per token. wmi_set_quant_resident(1) before whisper_init_* (or WMI_QUANT_RESIDENT=1) turns the resident copies on for models
  * loaded afterwards; it is off by default because those passes are bound by launch latency, not bytes, and the expansion costs
  * more than it saves today. wmi_set_quant_decode(state, 0) makes a state read the fp16 copies although blocks are resident. */
+/* wmi_set_decoder_lanes(state, 2): decoder passes of 32 rows or more run as two halves of their rows on two HIP streams (a row's
+ * results do not depend on which rows share its launches, so the outcome is the same to the bit). Off by default (1 lane): the
+ * half-size launches take as long as the full-size ones (they are bound by their own dependent chains) but did not overlap on
+ * the boxes this was measured on. */
+WHISPER_API int wmi_set_decoder_lanes(struct whisper_state *state, int n);
 WHISPER_API void wmi_set_quant_resident(int on);
 WHISPER_API int wmi_set_quant_decode(struct whisper_state *state, int on);
 WHISPER_API int wmi_get_host_timings(struct whisper_state *state, double *out /* [6] */);

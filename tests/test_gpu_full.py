@@ -401,6 +401,27 @@ def test_window_memo_on_a_growing_recording(wr, oracle, model_path, arch, lang):
     memo.free(); ctx.free()
 
 
+@pytest.mark.parametrize("arch", ["mini", "mini768"])
+def test_decoder_row_lanes_do_not_change_results(wr, model_path, arch):
+    """A decoder pass of 32 rows or more runs as two halves of its rows on two HIP streams. No kernel's arithmetic depends on the
+    rows that share its launch, so one lane and two lanes return the same tokens, times and log-probabilities to the bit --
+    greedy (one row per utterance) and beam search (three rows per utterance, cut between utterances), ragged clips."""
+    ctx = wr.WhisperContext(model_path(arch, decisive=4.0, style="varied"))
+    pcms = [synth_pcm(300 + i, int(16000 * (3.0 + (i * 7) % 27))) for i in range(40)]
+    for strategy in (wr.SamplingStrategy.Greedy(1), wr.SamplingStrategy.BeamSearch(3, -1.0)):
+        fp = wr.FullParams(strategy); fp.set_temperature_inc(0.0); fp.set_language("en")
+        out = {}
+        for lanes in (1, 2):
+            st = ctx.create_batch_state(len(pcms), 3, 16)
+            st.set_decoder_lanes(lanes)
+            st.full_batch(fp, pcms)
+            out[lanes] = [[(g.t0, g.t1, tuple(g.tokens), tuple(np.float32(p).tobytes() for p in g.plog)) for g in st.batch_segments(u)] for u in range(len(pcms))]
+            st.free()
+        assert out[1] == out[2]
+        assert sum(len(s[2]) for u in out[1] for s in u) > 200
+    ctx.free()
+
+
 def test_two_states_on_two_threads(wr, model_path):
     """Handy calls the engine from whatever thread has work (tokio blocking tasks, the live-coaching thread; reference
     transcription.rs:383, live_coaching.rs:70, discord_conversation.rs:475): two states of one context running at the
