@@ -284,6 +284,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    host_t0 = st.host_timings()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         toks = step()
@@ -291,6 +292,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    host_t = st.host_timings()
     roofline_from = "HIP events around the class inside the timed region"
     if not events_in_timed:
         st.set_profiling_classes([dom])
@@ -405,6 +407,8 @@ def main():
                          "algorithmic_work_per_launch": g["work"] / max(g["launches"], 1),
                          "avg_launch_ms": g["ms"] / max(g["launches"], 1), "launches": g["launches"], "measured": roofline_from},
             "kernel_classes": per_class,
+            # where the host thread spent the timed steps (ms per step): launching decoder passes vs waiting for them
+            "host": {k: (host_t[k] - host_t0[k]) / args.steps for k in ("mel_ms", "encode_launch_ms", "decode_launch_ms", "decode_wait_ms", "passes")},
         }
         if strong is not None:
             line["strong_scaling"] = strong
