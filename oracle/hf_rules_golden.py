@@ -166,13 +166,46 @@ def part_b():
     return out
 
 
+def part_c():
+    """Language detection as transformers does it (WhisperGenerationMixin.detect_language: one decoder step on the start token,
+    the logits of the language tokens only): those logits for every clip, multilingual vocabularies. whisper.cpp's
+    whisper_lang_auto_detect takes the softmax over the same tokens."""
+    import torch
+    from oracle.hf_golden import hf_mel, hf_model_from_ggml
+    torch.set_grad_enabled(False)
+    out = {}
+    for arch, V in VOCABS.items():
+        if V < 51865:
+            continue
+        ids = gf.special_token_ids(V)
+        n_lang = V - 51765 - 1
+        path = os.path.join(tempfile.gettempdir(), f"wmi_{arch}_varied.bin")
+        gf.write_synthetic_model(path, arch, seed=0, decisive=4.0, style="varied")
+        hf, _ = hf_model_from_ggml(path)
+        for seed, secs in SEQ_CLIPS:
+            pcm = synth_pcm(seed, int(round(secs * 16000)))
+            feats = torch.from_numpy(hf_mel(pcm, 128 if V == 51866 else 80)[None])
+            logits = hf(input_features=feats, decoder_input_ids=torch.tensor([[ids["sot"]]])).logits[0, -1]
+            lang = logits[ids["sot"] + 1: ids["sot"] + 1 + n_lang].numpy().astype(np.float32)
+            out[f"{arch}/s{seed}"] = lang
+            top = np.argsort(-lang)[:2]
+            print(f"C {arch:9s} clip {seed}: language {int(top[0])} (logit {lang[top[0]]:.3f}), runner-up {int(top[1])} ({lang[top[1]]:.3f})")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true")
+    ap.add_argument("--only-lang", action="store_true", help="regenerate the language-detection fixture only")
     args = ap.parse_args()
-    a, b = part_a(), part_b()
+    c = part_c()
     if args.write:
         os.makedirs(GOLDEN, exist_ok=True)
+        np.savez_compressed(os.path.join(GOLDEN, "hf_lang.npz"), **c)
+    if args.only_lang:
+        return
+    a, b = part_a(), part_b()
+    if args.write:
         np.savez_compressed(os.path.join(GOLDEN, "hf_rules.npz"), **a)
         np.savez_compressed(os.path.join(GOLDEN, "hf_sequences.npz"), **b)
         print("wrote", GOLDEN)

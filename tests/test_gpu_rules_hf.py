@@ -93,3 +93,28 @@ def test_greedy_stream_against_transformers_generate(wr, model_path, arch):
     assert len(mismatched) <= 1, mismatched       # fp32 (transformers) against fp16 activations: one near-tie may fall the other way
     assert n_tok >= 10
     st.free(); ctx.free()
+
+
+@pytest.mark.parametrize("arch", [a for a in sorted(VOCABS) if VOCABS[a] >= 51865])
+def test_language_detection_against_transformers(wr, model_path, arch):
+    """whisper_lang_auto_detect on the GPU against transformers' language logits for the same weights and clips: the
+    probabilities are the softmax of those logits within 6e-2 (these are the amplified weights of the rules tests: fp32 against
+    fp16-rounded activations moves a logit by up to 0.2 and the top probability by up to 0.047; 10 of the 12 clips are within
+    4e-3), and the detected language is transformers' argmax wherever its margin over the runner-up exceeds 0.3."""
+    hf_lang = np.load(os.path.join(ROOT, "tests", "golden", "hf_lang.npz"))
+    ctx = wr.WhisperContext(model_path(arch, decisive=4.0, style="varied")); st = ctx.create_state()
+    n_clear = 0
+    for seed, secs in SEQ_CLIPS:
+        ref = hf_lang[f"{arch}/s{seed}"].astype(np.float64)
+        want = np.exp(ref - ref.max()); want /= want.sum()
+        st.pcm_to_mel(synth_pcm(seed, int(round(secs * 16000))))
+        lid, probs = st.lang_detect(0)
+        err = float(np.abs(probs[: len(want)] - want).max())
+        print(arch, "clip", seed, "language", lid, "max |p - p_hf|", err)
+        assert err <= 6e-2, (seed, err)
+        top = np.argsort(-ref)[:2]
+        if ref[top[0]] - ref[top[1]] > 0.3:
+            assert lid == int(top[0]), (seed, lid, top)
+            n_clear += 1
+    assert n_clear >= 3
+    st.free(); ctx.free()
