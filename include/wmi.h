@@ -134,6 +134,37 @@ WHISPER_API void wmi_set_quant_resident(int on);
 WHISPER_API int wmi_set_quant_decode(struct whisper_state *state, int on);
 WHISPER_API int wmi_get_host_timings(struct whisper_state *state, double *out /* [6] */);
 
+/* ---- The step in front of the path, for bulk files: resample to 16 kHz frames + voice-activity gate ----------------------
+ * Handy's recorder does this per 30 ms of microphone audio on the CPU; an offline driver with hours of 44.1 / 48 kHz
+ * files in device memory calls these instead and hands the result to wmi_full_batch(..., samples_on_device = 1). The speech
+ * probability per frame (Silero, run by the vad-rs crate in the reference) stays with the caller. All device pointers are on the
+ * current HIP device; `stream` is a hipStream_t or NULL. */
+
+/* FrameResampler::new(in_hz, 16000, 30 ms) + push(all samples) + finish()
+ * (reference: src-tauri/src/audio_toolkit/audio/resampler.rs:16-98; the arithmetic is rubato 0.16.2's FftFixedIn<f32> with a
+ * 1024-sample chunk, resampler.rs:5,24). wmi_ingest_n_frames: how many 480-sample frames n_in samples at in_hz give, -1 for bad
+ * arguments. wmi_ingest_resample: writes those frames (the last one zero-padded) to frames_dev; enqueues on `stream` and
+ * returns. 0 ok, -1 bad arguments, -2 n_frames_cap too small, -3 rate not supported (the transform sizes must factor into
+ * 2, 3, 5, 7 and fit the LDS: every rate from 8 to 48 kHz in common use does, 96 kHz does not), -4 HIP error. */
+WHISPER_API long long wmi_ingest_n_frames(int in_hz, long long n_in);
+WHISPER_API int wmi_ingest_resample(const float *pcm_dev, long long n_in, int in_hz, float *frames_dev, long long n_frames_cap, void *stream);
+
+/* SmoothedVad::push_frame over a whole recording, then the recorder's handle_frame
+ * (reference: src-tauri/src/audio_toolkit/vad/smoothed.rs:41-96, audio_toolkit/audio/recorder.rs:290-295;
+ * managers/audio.rs:121-123 uses prefill 15, hangover 15, onset 2 on `probability > 0.3`). Host only. is_voice[i] != 0: the
+ * detector called frame i speech. Returns the number of frames appended to the output and writes the source frame of each, in
+ * order, to src_out (up to cap; a frame still in the pre-roll buffer when speech starts again is appended again, as in the
+ * reference). -1 for bad arguments. */
+WHISPER_API long long wmi_ingest_gate_plan(const unsigned char *is_voice, long long n_frames, int prefill, int hangover, int onset,
+                                           long long *src_out, long long cap);
+
+/* The gather: out_dev = the frames src[0..n_src) of frames_dev back to back, and, when that is less than one second but not
+ * empty, zeros up to 1.25 s (reference: src-tauri/src/managers/audio.rs:402-411). src is in host memory; both device pointers
+ * 16-byte aligned. *n_out = samples written. Waits for `stream`. 0 ok, -1 bad arguments, -2 out_cap too small (*n_out says what
+ * is needed), -4 HIP error. */
+WHISPER_API int wmi_ingest_gather(const float *frames_dev, long long n_frames, const long long *src, long long n_src, float *out_dev,
+                                  long long out_cap, long long *n_out, void *stream);
+
 WHISPER_API const char *wmi_version(void);
 
 #ifdef __cplusplus

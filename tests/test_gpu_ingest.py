@@ -1,0 +1,115 @@
+"""GPU parity of the step in front of the path (resample to 16 kHz frames, gather behind the smoothed gate) against the CPU
+restatement in oracle/ingest_oracle.py, through the C ABI (wmi_ingest_*)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from handy_amd.synth import synth_pcm    # noqa: E402
+from oracle import ingest_oracle as io    # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ing():
+    import torch
+    assert torch.cuda.is_available()
+    from handy_amd import ingest
+    return ingest
+
+
+def _dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+@pytest.mark.parametrize("hz", [48000, 44100, 32000, 24000, 22050, 11025, 8000, 16000])
+def test_resample_frames_match_restatement(ing, hz):
+    """fp32 transforms of up to 6174 points against the float64 restatement: |x| <= 1 in, error <= 6e-7 (observed <= 2.4e-7).
+    Lengths around every boundary: empty, under one chunk, whole chunks, one sample either side of a transform block, long."""
+    n_in, _ = io.fft_sizes(hz)
+    rs = ing.FrameResampler(hz)
+    worst = 0.0
+    for k, n in enumerate([0, 1, 1023, 1024, 1025, n_in - 1, n_in, n_in + 1, 2 * n_in, 3 * n_in + 7, 5 * n_in, 100000, 30 * hz + 13]):
+        x = synth_pcm(100 + k, n) * 4.0 if n else np.zeros(0, dtype=np.float32)
+        ref = io.resample_frames(x, hz)
+        got = rs.process(_dev(x)).cpu().numpy()
+        assert got.shape == ref.shape, (hz, n, got.shape, ref.shape)
+        if ref.size:
+            err = float(np.abs(got - ref).max())
+            worst = max(worst, err)
+            assert err <= 6e-7, (hz, n, err)
+            if hz == 16000:
+                assert np.array_equal(got, ref)
+    print(hz, "max |gpu - restatement|", worst)
+
+
+def test_resample_is_the_same_on_every_call_and_rejects_what_it_cannot_do(ing):
+    """Two addends per output sample: the sum does not depend on which workgroup arrives first. 96 kHz would need a 12288-point
+    transform pair (196 KB of LDS): refused with -3, nothing written."""
+    import ctypes as C
+    import torch
+    x = _dev(synth_pcm(7, 48000 * 20))
+    rs = ing.FrameResampler(48000)
+    a = rs.process(x)
+    for _ in range(3):
+        assert torch.equal(rs.process(x), a)
+    L = rs.L
+    out = torch.zeros(4800, device="cuda")
+    assert L.wmi_ingest_resample(C.c_void_p(x.data_ptr()), 10000, 96000, C.c_void_p(out.data_ptr()), 10, None) == -3
+    assert L.wmi_ingest_resample(C.c_void_p(x.data_ptr()), 48000, 48000, C.c_void_p(out.data_ptr()), 3, None) == -2
+    assert L.wmi_ingest_resample(None, 48000, 48000, C.c_void_p(out.data_ptr()), 1000, None) == -1
+    torch.cuda.synchronize()
+    assert not out.any()
+
+
+def test_gate_and_gather_match_restatement(ing):
+    rng = np.random.default_rng(3)
+    frames = rng.standard_normal((700, 480)).astype(np.float32)
+    fd = _dev(frames)
+    for prefill, hangover, onset in [(15, 15, 2), (10, 10, 2), (0, 0, 1), (3, 1, 2)]:
+        for p in (0.0, 0.02, 0.3, 0.9):
+            prob = rng.random(700) * (p > 0) + (p - 0.5)
+            ref, ref_src = io.gate_frames(frames, prob, 0.3, prefill, hangover, onset)
+            vad = ing.SmoothedVad(prefill, hangover, onset)
+            src = vad.plan(prob > 0.3)
+            assert np.array_equal(src, ref_src)
+            got = vad.gather(fd, src).cpu().numpy()
+            assert got.shape == ref.shape and np.array_equal(got, ref), (prefill, hangover, onset, p)
+    # a clip under one second is padded to 1.25 s (managers/audio.rs:402-411); nothing stays nothing
+    vad = ing.SmoothedVad(2, 1, 2)
+    prob = np.zeros(700); prob[100:104] = 1.0
+    got = vad.gather(fd, vad.plan(prob > 0.3)).cpu().numpy()
+    ref, _ = io.gate_frames(frames, prob, 0.3, 2, 1, 2)
+    assert len(got) == 20000 and np.array_equal(got, ref)
+    assert vad.gather(fd, vad.plan(np.zeros(700, dtype=bool))).numel() == 0
+
+
+def test_ingest_feeds_the_engine_from_device_memory(ing, model_path, oracle):
+    """A 48 kHz recording with a silent stretch: resample + gate on the GPU, transcribe from device memory; the oracle transcribes
+    what the CPU restatement of the same steps produces. Energy per frame stands in for Silero (the caller's part)."""
+    import torch
+    from handy_amd import whisper_rs as wr
+    hz = 48000
+    x = synth_pcm(31, 12 * hz) * 3.0
+    x[4 * hz: 7 * hz] *= 1e-4                                  # three quiet seconds
+    energy = lambda fr: np.sqrt((np.asarray(fr.cpu() if hasattr(fr, "cpu") else fr, dtype=np.float64) ** 2).mean(axis=1)) * 20.0
+    speech, src = ing.ingest(_dev(x), hz, energy)
+    ref_frames = io.resample_frames(x, hz)
+    ref_speech, ref_src = io.gate_frames(ref_frames, energy(ref_frames))
+    assert np.array_equal(src, ref_src) and 0 < len(src) < ref_frames.shape[0] - 60
+    assert np.abs(speech.cpu().numpy() - ref_speech).max() <= 6e-7
+    path = model_path("micro.en", decisive=4.0)
+    ctx = wr.WhisperContext(path); st = ctx.create_state()
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0)
+    st.full_batch_device(fp, [speech.data_ptr()], [speech.numel()])
+    got = st.batch_tokens(0)
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    op = oracle.default_params(0); op.temperature_inc = 0.0; op.best_of = 1
+    ref = [t for s in ost.full(op, ref_speech) for t in s["tokens"]]
+    assert got == ref and len(got) > 0
+    st.free(); ctx.free(); ost.close(); om.close()
