@@ -30,7 +30,7 @@ constexpr int kOutHz = 16000;       // constants::WHISPER_SAMPLE_RATE
 constexpr int kChunkIn = 1024;      // resampler.rs:5
 constexpr int kFrame = 480;         // 30 ms at 16 kHz (recorder.rs:260-264)
 constexpr int kMaxStages = 16;
-constexpr int kThreads = 512;
+constexpr int kThreads = 1024;
 constexpr size_t kMaxLds = 160 * 1024 - 1024;
 
 struct FftPlan {
@@ -41,9 +41,8 @@ struct FftPlan {
 struct ResamplePlan {               // passed to the kernel by value
     int n_in, n_out, new_len;       // fft_size_in, fft_size_out, bins kept
     FftPlan fwd, inv;               // 2 n_in and 2 n_out points
-    const float2 *tw_fwd;           // exp(-2 pi i m / (2 n_in)), m < 2 n_in
-    const float2 *tw_inv;           // exp(+2 pi i m / (2 n_out)), m < 2 n_out
-    const float2 *filt;             // the filter's transform, bins 0 .. new_len-1
+    const float2 *tables;           // exp(-2 pi i m / (2 n_in)), m < n_in | exp(+2 pi i m / (2 n_out)), m < n_out | the filter's
+                                    // transform, bins 0 .. new_len-1 (the second half of a twiddle table is minus the first)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -101,89 +100,154 @@ __device__ __forceinline__ void dft_small(float2 (&v)[R]) {
     }
 }
 
-// One Stockham pass: butterfly j takes in[j + r n/R] times tw^(r (j mod Ns)) and writes out[(j - j mod Ns) R + j mod Ns + r Ns].
-template <int R, bool INV>
-__device__ __forceinline__ void fft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, int n, int Ns, const float2 *__restrict__ tw, int tid) {
-    const int m = n / R;
-    const int tstep = n / (Ns * R);
-    for (int j = tid; j < m; j += kThreads) {
-        const int k = j % Ns;
-        float2 v[R];
+// Where a pass reads from and writes to. The first forward pass takes the PCM of the two blocks straight from global memory
+// (the upper half of the zero-padded input is never stored anywhere), the last forward pass multiplies with the filter and
+// drops or moves the bins as it writes, the last inverse pass adds the halves and writes the output samples.
+struct LdsSrc {
+    const float2 *p;
+    __device__ __forceinline__ float2 operator()(int i) const { return p[i]; }
+};
+struct PcmSrc {
+    const float *p0, *p1;
+    int left0, left1;                   // samples of block 0 / block 1 that exist (0 .. n_in)
+    __device__ __forceinline__ float2 operator()(int i) const {
+        float2 v = make_float2(0.0f, 0.0f);
+        if (i < left0) v.x = p0[i];
+        if (i < left1) v.y = p1[i];
+        return v;
+    }
+};
+struct LdsSink {
+    float2 *p;
+    template <int R>
+    __device__ __forceinline__ void put(int o, int Ns, const float2 (&v)[R]) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r) p[o + r * Ns] = v[r];
+    }
+};
+// bins below new_len times the filter; their mirror images times its conjugate, moved to the end of the 2 n_out-point spectrum;
+// everything else is dropped
+struct SpectrumSink {
+    float2 *z;
+    const float2 *filt;
+    int new_len, n2i, n2o;
+    template <int R>
+    __device__ __forceinline__ void put(int o, int Ns, const float2 (&v)[R]) const {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float2 a = in[j + r * m];
-            if (r > 0 && k > 0) a = cmul(a, tw[r * k * tstep]);
-            v[r] = a;
+            const int k = o + r * Ns;
+            if (k < new_len) {
+                const float2 f = filt[k];
+                z[k] = cmul(v[r], f);
+                if (2 * k == n2i) z[n2o - k] = cmul(v[r], make_float2(f.x, -f.y));      // the input's Nyquist bin is its own mirror image (kept when interpolating)
+            } else {
+                const int kk = n2i - k;
+                if (kk < new_len) { const float2 f = filt[kk]; z[n2o - kk] = cmul(v[r], make_float2(f.x, -f.y)); }
+            }
+        }
+    }
+};
+// The last inverse pass has an even radix, so the thread that holds sample n of the result also holds sample n + n_out.
+struct OutSink {
+    float *o0, *o1;
+    int n_out;
+    bool has1, has2;
+    template <int R>
+    __device__ __forceinline__ void put(int o, int Ns, const float2 (&v)[R]) const {
+        if constexpr (R % 2 == 0) {
+#pragma unroll
+            for (int r = 0; r < R / 2; ++r) {
+                const int n = o + r * Ns;
+                const float2 h = v[r], t = v[r + R / 2];
+                atomicAdd(o0 + n, h.x);                             // + the tail of block 2w-1, from another workgroup
+                if (has1) o1[n] = h.y + t.x;
+                if (has2) atomicAdd(o1 + n_out + n, t.y);           // the tail of block 2w+1, for block 2w+2
+            }
+        }
+    }
+};
+
+// One Stockham pass: butterfly j takes in[j + r n/R] times tw^(r (j mod Ns)) and writes out[(j - j mod Ns) R + j mod Ns + r Ns].
+// tw is the first half of the table exp(-+2 pi i m / n) (the second half is minus the first).
+template <int R, bool INV, class Src, class Sink>
+__device__ __forceinline__ void fft_pass(int n, int Ns, const float2 *__restrict__ tw, int tid, const Src &src, const Sink &sink) {
+    const int m = n / R;
+    const int tstep = m / Ns;
+    const int half = n >> 1;
+    const float inv_ns = 1.0f / (float)Ns;
+    for (int j = tid; j < m; j += kThreads) {
+        const int k = j - (int)(((float)j + 0.5f) * inv_ns) * Ns;       // j mod Ns: j < 2^20, so the product is off by far less than 0.5 / Ns
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = src(j + r * m);
+        if (k > 0) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                const int mi = r * k * tstep;
+                const float2 w = tw[mi >= half ? mi - half : mi];
+                v[r] = cmul(v[r], mi >= half ? make_float2(-w.x, -w.y) : w);
+            }
         }
         dft_small<R, INV>(v);
-        const int o = (j - k) * R + k;
-#pragma unroll
-        for (int r = 0; r < R; ++r) out[o + r * Ns] = v[r];
+        sink.template put<R>((j - k) * R + k, Ns, v);
     }
 }
 
-// All passes of one transform between the two LDS buffers; returns the buffer that holds the result (natural order).
-template <bool INV>
-__device__ float2 *fft_run(float2 *src, float2 *dst, const FftPlan &fp, const float2 *__restrict__ tw, int tid) {
-    int Ns = 1;
-    for (int s = 0; s < fp.n_stage; ++s) {
-        const int R = fp.radix[s];
-        switch (R) {
-            case 4: fft_pass<4, INV>(src, dst, fp.n, Ns, tw, tid); break;
-            case 2: fft_pass<2, INV>(src, dst, fp.n, Ns, tw, tid); break;
-            case 3: fft_pass<3, INV>(src, dst, fp.n, Ns, tw, tid); break;
-            case 5: fft_pass<5, INV>(src, dst, fp.n, Ns, tw, tid); break;
-            default: fft_pass<7, INV>(src, dst, fp.n, Ns, tw, tid); break;
-        }
-        __syncthreads();
-        float2 *t = src; src = dst; dst = t;
-        Ns *= R;
+template <bool INV, class Src, class Sink>
+__device__ __forceinline__ void fft_pass_any(int R, int n, int Ns, const float2 *__restrict__ tw, int tid, const Src &src, const Sink &sink) {
+    switch (R) {
+        case 4: fft_pass<4, INV>(n, Ns, tw, tid, src, sink); break;
+        case 2: fft_pass<2, INV>(n, Ns, tw, tid, src, sink); break;
+        case 3: fft_pass<3, INV>(n, Ns, tw, tid, src, sink); break;
+        case 5: fft_pass<5, INV>(n, Ns, tw, tid, src, sink); break;
+        default: fft_pass<7, INV>(n, Ns, tw, tid, src, sink); break;
     }
-    return src;
 }
 
-// pcm[n_valid] (zeros beyond) -> out[n_blocks * n_out]: workgroup w resamples blocks 2w and 2w+1. `out` must be zero before
-// the launch: the first block of a pair shares its samples with the tail of the pair before it.
+// pcm[n_valid] (zeros beyond) -> out[n_blocks * n_out]: pair w is blocks 2w and 2w+1; the workgroups are persistent and stride over
+// the pairs with both twiddle tables and the filter in LDS. `out` must be zero before the launch: the first block of a pair
+// shares its samples with the tail of the pair before it. Both transforms have at least two passes (1024 points or more).
 __global__ __launch_bounds__(kThreads) void resample_blocks_kernel(const float *__restrict__ pcm, long long n_valid, ResamplePlan P, long long n_blocks, float *__restrict__ out) {
     extern __shared__ float2 lds[];
     const int n2i = 2 * P.n_in, n2o = 2 * P.n_out;
     const int nmax = n2i > n2o ? n2i : n2o;
     float2 *a = lds, *b = lds + nmax;
+    float2 *twf = b + nmax, *twi = twf + P.n_in, *filt = twi + P.n_out;
     const int tid = threadIdx.x;
-    const long long b0 = 2 * (long long)blockIdx.x, b1 = b0 + 1;
-    const bool has1 = b1 < n_blocks;
-    for (int i = tid; i < n2i; i += kThreads) {
-        float2 v = make_float2(0.0f, 0.0f);
-        if (i < P.n_in) {
-            const long long p0 = b0 * P.n_in + i, p1 = b1 * P.n_in + i;
-            if (p0 < n_valid) v.x = pcm[p0];
-            if (has1 && p1 < n_valid) v.y = pcm[p1];
+    for (int i = tid; i < P.n_in + P.n_out + P.new_len; i += kThreads) twf[i] = P.tables[i];
+    const long long n_pairs = (n_blocks + 1) / 2;
+    for (long long w = blockIdx.x; w < n_pairs; w += gridDim.x) {
+        const long long b0 = 2 * w, b1 = b0 + 1;
+        const bool has1 = b1 < n_blocks, has2 = b1 + 1 < n_blocks;
+        const long long l0 = n_valid - b0 * P.n_in, l1 = has1 ? n_valid - b1 * P.n_in : 0;
+        PcmSrc pcm_src;
+        pcm_src.p0 = pcm + b0 * P.n_in; pcm_src.p1 = pcm + (has1 ? b1 : b0) * P.n_in;
+        pcm_src.left0 = (int)(l0 < 0 ? 0 : l0 > P.n_in ? P.n_in : l0);
+        pcm_src.left1 = (int)(l1 < 0 ? 0 : l1 > P.n_in ? P.n_in : l1);
+        float2 *cur = a, *oth = b;
+        int Ns = 1;
+        fft_pass_any<false>(P.fwd.radix[0], n2i, Ns, twf, tid, pcm_src, LdsSink{cur});
+        Ns *= P.fwd.radix[0];
+        __syncthreads();
+        for (int s = 1; s + 1 < P.fwd.n_stage; ++s) {
+            fft_pass_any<false>(P.fwd.radix[s], n2i, Ns, twf, tid, LdsSrc{cur}, LdsSink{oth});
+            Ns *= P.fwd.radix[s];
+            __syncthreads();
+            float2 *t = cur; cur = oth; oth = t;
         }
-        a[i] = v;
-    }
-    __syncthreads();
-    float2 *X = fft_run<false>(a, b, P.fwd, P.tw_fwd, tid);
-    float2 *Z = X == a ? b : a;
-    // bins below new_len times the filter; their mirror images times its conjugate; everything else is dropped
-    for (int k = tid; k < n2o; k += kThreads) {
-        float2 z = make_float2(0.0f, 0.0f);
-        if (k < P.new_len) {
-            z = cmul(X[k], P.filt[k]);
-        } else {
-            const int kk = n2o - k;
-            if (kk >= 1 && kk < P.new_len) { const float2 f = P.filt[kk]; z = cmul(X[n2i - kk], make_float2(f.x, -f.y)); }
+        for (int k = P.new_len + tid; k <= n2o - P.new_len; k += kThreads) oth[k] = make_float2(0.0f, 0.0f);       // the bins nobody writes
+        fft_pass_any<false>(P.fwd.radix[P.fwd.n_stage - 1], n2i, Ns, twf, tid, LdsSrc{cur}, SpectrumSink{oth, filt, P.new_len, n2i, n2o});
+        __syncthreads();
+        { float2 *t = cur; cur = oth; oth = t; }
+        Ns = 1;
+        for (int s = 0; s + 1 < P.inv.n_stage; ++s) {
+            fft_pass_any<true>(P.inv.radix[s], n2o, Ns, twi, tid, LdsSrc{cur}, LdsSink{oth});
+            Ns *= P.inv.radix[s];
+            __syncthreads();
+            float2 *t = cur; cur = oth; oth = t;
         }
-        Z[k] = z;
-    }
-    __syncthreads();
-    float2 *Y = fft_run<true>(Z, X, P.inv, P.tw_inv, tid);
-    float *o0 = out + b0 * P.n_out, *o1 = out + b1 * P.n_out;
-    const bool has2 = b1 + 1 < n_blocks;
-    for (int n = tid; n < P.n_out; n += kThreads) {
-        const float2 h = Y[n], t = Y[P.n_out + n];
-        atomicAdd(o0 + n, h.x);                                 // + the tail of block 2w-1, from the workgroup before
-        if (has1) o1[n] = h.y + t.x;
-        if (has2) atomicAdd(o1 + P.n_out + n, t.y);             // the tail of block 2w+1, for block 2w+2
+        fft_pass_any<true>(P.inv.radix[P.inv.n_stage - 1], n2o, Ns, twi, tid, LdsSrc{cur}, OutSink{out + b0 * P.n_out, out + b1 * P.n_out, P.n_out, has1, has2});
+        __syncthreads();
     }
 }
 
@@ -198,16 +262,23 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(const float4 *__rest
     }
 }
 
-bool factor_radices(int n, FftPlan &fp) {
+// n = product of radices 4, 2, 3, 5, 7; even_last: the odd ones first and a 2 or 4 at the end (the pass that writes the output
+// samples needs sample n and sample n + n/2 in one thread).
+bool factor_radices(int n, FftPlan &fp, bool even_last) {
     fp.n = n; fp.n_stage = 0;
-    const int radices[5] = {4, 2, 3, 5, 7};
-    for (int r : radices)
-        while (n % r == 0) {
+    const int fwd_order[5] = {4, 2, 3, 5, 7}, inv_order[5] = {3, 5, 7, 2, 4};
+    int twos = 0;
+    while (n % 2 == 0) { ++twos; n /= 2; }
+    int count[8] = {0};
+    count[4] = twos / 2; count[2] = twos % 2;
+    for (int r : {3, 5, 7}) while (n % r == 0) { ++count[r]; n /= r; }
+    if (n != 1 || (even_last && twos == 0)) return false;
+    for (int r : (even_last ? inv_order : fwd_order))
+        for (int c = 0; c < count[r]; ++c) {
             if (fp.n_stage == kMaxStages) return false;
             fp.radix[fp.n_stage++] = r;
-            n /= r;
         }
-    return n == 1;
+    return fp.n_stage >= 2;
 }
 
 int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
@@ -225,6 +296,7 @@ void fft_sizes(int in_hz, int &n_in, int &n_out) {
 struct DevicePlan {
     ResamplePlan p{};
     size_t lds = 0;
+    int n_cu = 256;
     bool ok = false;
 };
 std::mutex g_plan_mu;
@@ -277,23 +349,25 @@ const DevicePlan *get_plan(int in_hz) {
     fft_sizes(in_hz, p.n_in, p.n_out);
     p.new_len = p.n_in > p.n_out ? p.n_out : p.n_in + 1;
     const int n2i = 2 * p.n_in, n2o = 2 * p.n_out;
-    dp.lds = (size_t)2 * (n2i > n2o ? n2i : n2o) * sizeof(float2);
-    if (!factor_radices(n2i, p.fwd) || !factor_radices(n2o, p.inv) || dp.lds > kMaxLds) {
+    dp.lds = ((size_t)2 * (n2i > n2o ? n2i : n2o) + p.n_in + p.n_out + p.new_len) * sizeof(float2);
+    if (!factor_radices(n2i, p.fwd, false) || !factor_radices(n2o, p.inv, true) || dp.lds > kMaxLds) {
         log_msg(2, "wmi_ingest: %d Hz needs transforms of %d and %d points (radices 2, 3, 5, 7 only, %zu bytes of LDS at most): not supported\n", in_hz, n2i, n2o, kMaxLds);
         return nullptr;
     }
     const double pi = 3.14159265358979323846;
-    std::vector<float2> host((size_t)n2i + n2o + p.new_len);
-    for (int m = 0; m < n2i; ++m) host[m] = make_float2((float)std::cos(2 * pi * m / n2i), (float)-std::sin(2 * pi * m / n2i));
-    for (int m = 0; m < n2o; ++m) host[n2i + m] = make_float2((float)std::cos(2 * pi * m / n2o), (float)std::sin(2 * pi * m / n2o));
+    std::vector<float2> host((size_t)p.n_in + p.n_out + p.new_len);
+    for (int m = 0; m < p.n_in; ++m) host[m] = make_float2((float)std::cos(2 * pi * m / n2i), (float)-std::sin(2 * pi * m / n2i));
+    for (int m = 0; m < p.n_out; ++m) host[p.n_in + m] = make_float2((float)std::cos(2 * pi * m / n2o), (float)std::sin(2 * pi * m / n2o));
     std::vector<float2> F;
     filter_spectrum(p.n_in, p.n_out, p.new_len, F);
-    for (int k = 0; k < p.new_len; ++k) host[(size_t)n2i + n2o + k] = F[k];
+    for (int k = 0; k < p.new_len; ++k) host[(size_t)p.n_in + p.n_out + k] = F[k];
     float2 *dev = nullptr;
     if (hipMalloc((void **)&dev, host.size() * sizeof(float2)) != hipSuccess) return nullptr;
     if (hipMemcpy(dev, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return nullptr; }
-    p.tw_fwd = dev; p.tw_inv = dev + n2i; p.filt = dev + n2i + n2o;
+    p.tables = dev;
     if (hipFuncSetAttribute((const void *)resample_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess) { (void)hipFree(dev); return nullptr; }
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) dp.n_cu = n_cu;
     dp.ok = true;
     return &dp;
 }
@@ -336,8 +410,8 @@ WHISPER_API int wmi_ingest_resample(const float *pcm_dev, long long n_in, int in
     if (!dp) return -3;
     if (hipMemsetAsync(frames_dev, 0, (size_t)n_frames * kFrame * sizeof(float), st) != hipSuccess) return -4;
     const long long n_blocks = n_stream / dp->p.n_out;
-    const long long n_wg = (n_blocks + 1) / 2;
-    if (n_wg > 0x7fffffffLL) return -2;
+    const long long n_pairs = (n_blocks + 1) / 2;
+    const long long n_wg = n_pairs < dp->n_cu ? n_pairs : dp->n_cu;             // one workgroup fills a CU's LDS
     hipLaunchKernelGGL(resample_blocks_kernel, dim3((unsigned)n_wg), dim3(kThreads), dp->lds, st, pcm_dev, n_in, dp->p, n_blocks, frames_dev);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
