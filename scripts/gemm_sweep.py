@@ -10,6 +10,8 @@ MROWS = int(os.environ.get('WMI_SWEEP_ROWS', '24000'))
 shapes = [(MROWS, 5120, 1280), (MROWS, 1280, 5120), (MROWS, 2560, 1280), (MROWS, 1280, 1280)]
 if os.environ.get('WMI_SWEEP_DEC'):       # the decoder's shapes: few rows, weights read once
     shapes = [(MROWS, 1280, 1280), (MROWS, 3840, 1280), (MROWS, 5120, 1280), (MROWS, 1280, 5120), (MROWS, 768, 768), (MROWS, 768, 3072)]
+if os.environ.get('WMI_SWEEP_SHAPES'):     # explicit shapes: "M,N,K;M,N,K;..."
+    shapes = [tuple(int(v) for v in t.split(',')) for t in os.environ['WMI_SWEEP_SHAPES'].split(';')]
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 9, 15]
 L.wmi_debug_gemm_variant_diff.restype = C.c_int
 L.wmi_debug_gemm_variant_diff.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
@@ -25,4 +27,4 @@ for (M, N, K) in shapes:
             ms = C.c_float()
             rc = L.wmi_bench_gemm(M, N, K, v, 10, C.byref(ms))
             tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12 if rc == 0 and ms.value > 0 else 0
-            print(f"M={M} N={N} K={K} round {rnd} variant {v} ({names[v]:15s}) rc={rc} {ms.value*1e3:8.1f} us {tf:7.1f} TF/s", flush=True)
+            print(f"M={M} N={N} K={K} round {rnd} variant {v} ({names.get(v, '?'):15s}) rc={rc} {ms.value*1e3:8.1f} us {tf:7.1f} TF/s", flush=True)
