@@ -205,6 +205,13 @@ extern "C" {
     pub fn wmi_set_window_cache(state: *mut whisper_state, max_windows: c_int);
     pub fn wmi_get_window_cache_stats(state: *mut whisper_state, hits: *mut i64, stores: *mut i64);
     pub fn wmi_batch_segment_text(state: *mut whisper_state, utt: c_int, seg: c_int) -> *const c_char;
+
+    // wmi.h: the recorder's resample + VAD gate for bulk files in device memory (audio_toolkit/audio/resampler.rs, vad/smoothed.rs)
+    pub fn wmi_ingest_n_frames(in_hz: c_int, n_in: i64) -> i64;
+    pub fn wmi_ingest_resample(pcm_dev: *const c_float, n_in: i64, in_hz: c_int, frames_dev: *mut c_float, n_frames_cap: i64, stream: *mut c_void) -> c_int;
+    pub fn wmi_ingest_gate_plan(is_voice: *const u8, n_frames: i64, prefill: c_int, hangover: c_int, onset: c_int, src_out: *mut i64, cap: i64) -> i64;
+    pub fn wmi_ingest_gather(frames_dev: *const c_float, n_frames: i64, src: *const i64, n_src: i64, out_dev: *mut c_float, out_cap: i64,
+                             n_out: *mut i64, stream: *mut c_void) -> c_int;
 }
 
 /// whisper-rs installs a ggml log hook through this symbol; the engine has no ggml, so it is a no-op
