@@ -1,7 +1,11 @@
 """Mirror of the reference's capture-side interface for bulk files, on the GPU: `FrameResampler`
 (src-tauri/src/audio_toolkit/audio/resampler.rs:7-99) and `SmoothedVad` (audio_toolkit/vad/smoothed.rs:5-105) over whole
-recordings in device memory, through the C ABI of libwhisper_mi355.so (`wmi_ingest_*`).  torch is used for device memory
-only.  The per-frame speech probability (Silero in the reference, silero.rs:41-50) comes from the caller."""
+recordings in device memory, through the C ABI of libwhisper_mi355.so (`wmi_ingest_*`).  The per-frame speech probability
+(Silero in the reference, silero.rs:41-50) comes from the caller.
+
+Device memory comes from the HIP runtime the library itself is linked against (`DeviceBuffer`); anything else that exposes
+`data_ptr()` and `numel()` (a torch CUDA tensor, say) is accepted as input or as `out=` too -- the caller then passes the
+stream its data lives on."""
 import ctypes as C
 from typing import Callable, Optional
 
@@ -12,9 +16,67 @@ from . import whisper_rs as wr
 WHISPER_SAMPLE_RATE = 16000
 FRAME_SAMPLES = 480         # 30 ms
 
+_hip = None
 
-def _ptr(t):
-    return C.c_void_p(t.data_ptr())
+
+def _runtime():
+    global _hip
+    if _hip is None:
+        wr.load_library()                              # the engine first: it brings in the runtime it was linked against
+        H = C.CDLL("libamdhip64.so.7")
+        H.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        H.hipFree.argtypes = [C.c_void_p]
+        H.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip = H
+    return _hip
+
+
+class DeviceBuffer:
+    """float32 array in device memory on the current HIP device."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.n = int(np.prod(self.shape)) if self.shape else 1
+        p = C.c_void_p()
+        rc = _runtime().hipMalloc(C.byref(p), max(self.n, 1) * 4)
+        if rc != 0 or not p.value:
+            raise wr.WhisperError(f"hipMalloc of {self.n * 4} bytes failed: {rc}")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = cls(a.shape)
+        if a.size and _runtime().hipMemcpy(b.ptr, a.ctypes.data, a.nbytes, 1) != 0:
+            raise wr.WhisperError("hipMemcpy to the device failed")
+        return b
+
+    def numpy(self, n: Optional[int] = None) -> np.ndarray:
+        """Copy back (waits for the null stream's work). n: only the first n floats, flat."""
+        out = np.empty(self.shape if n is None else (int(n),), dtype=np.float32)
+        if out.size and _runtime().hipMemcpy(out.ctypes.data, self.ptr, out.nbytes, 2) != 0:
+            raise wr.WhisperError("hipMemcpy from the device failed")
+        return out
+
+    def data_ptr(self): return self.ptr
+    def numel(self): return self.n
+
+    def free(self):
+        if self.ptr:
+            _runtime().hipFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _as_device(x):
+    if hasattr(x, "data_ptr") and hasattr(x, "numel"):
+        return x
+    return DeviceBuffer.from_numpy(x)
 
 
 class FrameResampler:
@@ -31,18 +93,20 @@ class FrameResampler:
     def n_frames(self, n_in: int) -> int:
         return int(self.L.wmi_ingest_n_frames(self.in_hz, int(n_in)))
 
-    def process(self, pcm_dev):
-        """pcm_dev: 1-D float32 CUDA tensor at in_hz -> [n_frames, 480] float32 CUDA tensor at 16 kHz."""
-        import torch
-        if not (pcm_dev.is_cuda and pcm_dev.dtype == torch.float32 and pcm_dev.dim() == 1 and pcm_dev.is_contiguous()):
-            raise ValueError("expected a contiguous 1-D float32 CUDA tensor")
-        nf = self.n_frames(pcm_dev.numel())
-        out = torch.empty((nf, FRAME_SAMPLES), dtype=torch.float32, device=pcm_dev.device)
-        with torch.cuda.device(pcm_dev.device):
-            st = torch.cuda.current_stream().cuda_stream
-            rc = self.L.wmi_ingest_resample(_ptr(pcm_dev), pcm_dev.numel(), self.in_hz, _ptr(out), nf, C.c_void_p(st))
+    def process(self, pcm, out=None, stream: int = 0):
+        """pcm: float32 samples at in_hz (numpy array -> uploaded, or device memory) -> [n_frames, 480] float32 at 16 kHz in
+        device memory (`out`, or a new DeviceBuffer). Enqueued on `stream` (a hipStream_t value; 0 = the null stream)."""
+        x = _as_device(pcm)
+        nf = self.n_frames(x.numel())
+        if out is None:
+            out = DeviceBuffer((nf, FRAME_SAMPLES))
+        elif out.numel() < nf * FRAME_SAMPLES:
+            raise ValueError("out is too small")
+        rc = self.L.wmi_ingest_resample(C.c_void_p(x.data_ptr()), x.numel(), self.in_hz, C.c_void_p(out.data_ptr()), nf, C.c_void_p(stream))
         if rc != 0:
             raise wr.WhisperError(f"wmi_ingest_resample failed: {rc}")
+        if not (x is pcm):
+            out._keep = x                  # the upload must outlive the kernel
         return out
 
 
@@ -64,30 +128,28 @@ class SmoothedVad:
         self.L.wmi_ingest_gate_plan(vp, len(v), self.prefill, self.hangover, self.onset, src.ctypes.data_as(C.POINTER(C.c_longlong)), int(n))
         return src[: int(n)]
 
-    def gather(self, frames_dev, src: np.ndarray):
-        """frames_dev [n_frames, 480] on the device, src from `plan` -> 1-D float32 CUDA tensor of the speech samples
-        (clips under one second padded to 1.25 s, as stop_recording does)."""
-        import torch
+    def gather(self, frames, src: np.ndarray, stream: int = 0):
+        """frames [n_frames, 480] in device memory, src from `plan` -> (DeviceBuffer, number of speech samples in it); clips under
+        one second are padded to 1.25 s, as stop_recording does. Waits for `stream`."""
         src = np.ascontiguousarray(src, dtype=np.int64)
         total = len(src) * FRAME_SAMPLES
         cap = max(total, WHISPER_SAMPLE_RATE * 5 // 4)
-        out = torch.empty(cap, dtype=torch.float32, device=frames_dev.device)
+        out = DeviceBuffer(cap)
         n_out = C.c_longlong(0)
-        with torch.cuda.device(frames_dev.device):
-            st = torch.cuda.current_stream().cuda_stream
-            rc = self.L.wmi_ingest_gather(_ptr(frames_dev), frames_dev.shape[0], src.ctypes.data_as(C.POINTER(C.c_longlong)), len(src),
-                                          _ptr(out), cap, C.byref(n_out), C.c_void_p(st))
+        rc = self.L.wmi_ingest_gather(C.c_void_p(frames.data_ptr()), frames.numel() // FRAME_SAMPLES, src.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                      len(src), C.c_void_p(out.data_ptr()), cap, C.byref(n_out), C.c_void_p(stream))
         if rc != 0:
             raise wr.WhisperError(f"wmi_ingest_gather failed: {rc}")
-        return out[: n_out.value]
+        return out, int(n_out.value)
 
 
-def ingest(pcm_dev, in_hz: int, speech_prob: Callable, threshold: float = 0.3, vad: Optional[SmoothedVad] = None):
+def ingest(pcm, in_hz: int, speech_prob: Callable, threshold: float = 0.3, vad: Optional[SmoothedVad] = None):
     """One recording from its native rate to the samples Handy's recorder would hand to `transcribe`
-    (managers/audio.rs:121-123 defaults): resample, ask `speech_prob(frames_dev) -> per-frame probabilities` (host array),
-    gate, gather."""
-    frames = FrameResampler(in_hz).process(pcm_dev)
+    (managers/audio.rs:121-123 defaults): resample, ask `speech_prob(frames as a host array) -> per-frame probabilities`,
+    gate, gather. Returns (speech DeviceBuffer, number of samples, source frames)."""
+    frames = FrameResampler(in_hz).process(pcm)
     vad = vad or SmoothedVad()
-    prob = np.asarray(speech_prob(frames), dtype=np.float32)
+    prob = np.asarray(speech_prob(frames.numpy()), dtype=np.float32)
     src = vad.plan(prob > threshold)
-    return vad.gather(frames, src), src
+    speech, n = vad.gather(frames, src)
+    return speech, n, src

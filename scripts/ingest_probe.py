@@ -19,14 +19,16 @@ for hz in (48000, 44100):
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     x = (torch.rand(n, device="cuda", generator=g) - 0.5) * 0.2
     rs = ingest.FrameResampler(hz)
+    out = torch.empty((rs.n_frames(n), 480), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream          # torch is imported first here, so both share its HIP runtime's stream
     for _ in range(2):
-        out = rs.process(x)
+        rs.process(x, out=out, stream=st)
     torch.cuda.synchronize()
     iters = 10
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
     ev[0].record()
     for i in range(iters):
-        out = rs.process(x)
+        rs.process(x, out=out, stream=st)
         ev[i + 1].record()
     torch.cuda.synchronize()
     ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(iters)]
@@ -34,7 +36,9 @@ for hz in (48000, 44100):
     alg = 4.0 * (n + out.numel())
     xs = x[: 60 * hz].cpu().numpy()
     t0 = time.perf_counter(); ref = io.resample_frames(xs, hz); cpu_s = time.perf_counter() - t0
-    err = float(np.abs(rs.process(x[: 60 * hz]).cpu().numpy() - ref).max())
+    o60 = torch.empty(ref.shape, dtype=torch.float32, device="cuda")
+    rs.process(x[: 60 * hz].contiguous(), out=o60, stream=st)
+    err = float(np.abs(o60.cpu().numpy() - ref).max())
     print(json.dumps({
         "metric": f"RTFx (audio-sec/sec), resample {hz} Hz -> 16 kHz frames", "value": secs / (avg * 1e-3), "unit": "audio-sec/sec",
         "ms_per_step": avg, "ms_min": float(np.min(ms)), "dtype": "f32", "data": "synthetic",
