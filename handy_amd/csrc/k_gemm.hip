@@ -788,6 +788,9 @@ int skinny_steps(int N, int K);
 template <class Epi>
 static bool dispatch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, bool dec = false) {
     const long big = (long)((M + 255) / 256) * (N / 128);
+    // one clip's encoder (1500 rows) at N = 4d: 6 x 20 tiles of 256 x 256 leave half the CUs idle, 6 x 40 of 256 x 128 fill them
+    // (large-v3-turbo fc1: 34.5 -> 27.0 us; same bits)
+    if (M <= 1536 && N % 128 == 0 && N <= 8192 && big >= 192) return launch<256, 128, 4, 2, 3, Epi>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 256 == 0 && big >= 192 && K >= 2 * BK) return launch8<Epi>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 256 == 0 && big >= 192) return launch<256, 256, 2, 4, 2, Epi, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 128 == 0 && M >= 192 && big >= 128) return launch<256, 128, 4, 2, 3, Epi>(A, lda, W, ldw, M, N, K, epi, st);
