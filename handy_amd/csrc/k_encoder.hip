@@ -199,7 +199,7 @@ bool layer_norm_variant(int variant, const float *x, const float *w, const float
 #endif  // WMI_HARNESS
 
 // ------------------------------------------------------------------------------------------ attention
-// Non-causal softmax(Q K^T) V over T keys, heads of 64. Q is pre-scaled by 1/8 (exact in fp16).
+// Non-causal softmax(Q K^T) V over T keys, heads of 64. Q is pre-scaled by log2(e)/8 (kEncQScale): scores in log2 units.
 // Workgroup = 4 waves = 128 query rows of one (utterance, head); each wave owns 32 rows and walks
 // the keys in tiles of 64 staged through LDS (register-staged, double-buffered, XOR-swizzled).
 //   S^T = K Q^T      v_mfma_f32_32x32x16_f16, K rows as the A operand: a lane then holds scores of
@@ -209,7 +209,6 @@ bool layer_norm_variant(int variant, const float *x, const float *w, const float
 //                    operand; V arrives pre-transposed ([dh][key], written that way by the QKV GEMM
 //                    epilogue), read in the k-order the accumulator layout implies.
 // Bound: MFMA (4*T*T*64 flop per head). The output tile goes through LDS so rows are stored whole.
-constexpr float kLog2e = 1.4426950408889634f;
 
 __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restrict__ Q, const f16 *__restrict__ K, const f16 *__restrict__ Vt,
                                                             f16 *__restrict__ att, int H, int T, int Tp) {
@@ -260,29 +259,33 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
         }
     };
 
-    f32x16 o0, o1;
+    f32x16 o0, o1, minit;                         // minit = -m_run in all 16 elements: the C operand of a tile's first MFMA
 #pragma unroll
-    for (int i = 0; i < 16; i++) { o0[i] = 0.0f; o1[i] = 0.0f; }
-    float m_run = -INFINITY, l_run = 0.0f;
+    for (int i = 0; i < 16; i++) { o0[i] = 0.0f; o1[i] = 0.0f; minit[i] = 0.0f; }
+    float m_run = 0.0f, l_run = 0.0f;             // m_run: the query's reference exponent (log2 units), set by tile 0
     const int n_tiles = (T + 63) / 64;
     load_tile(0);
     store_tile(0);
     __syncthreads();
-    // one key tile; MASK = the tile holds keys past T (only ever the last one), kept out of the steady-state loop
-    auto tile = [&](int kt, auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
+    // One key tile. Q carries log2(e)/8, so K Q^T is the score in log2 units, and the accumulators start at -m_run: the
+    // MFMAs leave s - m_run, the exponent's argument, with no further arithmetic. The reference m_run is the maximum of
+    // tile 0 and moves only when a later tile's maximum exceeds it by more than kDefer (then p <= 2^kDefer = 256: fp16
+    // holds that at full relative precision and the sums are fp32, so the result is the same softmax, rounded alike).
+    // MASK = the tile holds keys past T (only ever the last one); FIRST = tile 0.
+    constexpr float kDefer = 8.0f;
+    auto tile = [&](int kt, auto mask_tag, auto first_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value, FIRST = decltype(first_tag)::value;
         const char *kb = smem + (kt & 1) * 16384, *vb = kb + 8192;
         if (kt + 1 < n_tiles) load_tile(kt + 1);
         f32x16 s[2];
 #pragma unroll
         for (int kh = 0; kh < 2; kh++) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) s[kh][i] = 0.0f;
             const int row = kh * 32 + r, sw = (row >> 1) & 7;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 const f16x8 kf = *(const f16x8 *)(kb + row * 128 + (((2 * ks + h) ^ sw) << 4));
-                s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kh], 0, 0, 0);
+                if (ks == 0) s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], minit, 0, 0, 0);
+                else s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kh], 0, 0, 0);
             }
         }
         if (MASK) {
@@ -300,26 +303,33 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
 #pragma unroll
             for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[kh][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float mb = m_new * kLog2e;
+        // move the reference (wave-uniform branch): always at tile 0, later only past the deferral threshold
+        if (FIRST || __builtin_amdgcn_ballot_w64(mx > kDefer) != 0) {
+            const float delta = FIRST ? mx : fmaxf(mx, 0.0f);      // queries whose maximum did not grow keep theirs (alpha == 1)
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) s[kh][i] -= delta;
+            m_run += delta;
+#pragma unroll
+            for (int i = 0; i < 16; i++) minit[i] = -m_run;
+            if (!FIRST) {
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+            }
+        }
         float lsum = 0.0f;
         f16x8 pf[2][2];
 #pragma unroll
         for (int kh = 0; kh < 2; kh++)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const float p = __builtin_amdgcn_exp2f(s[kh][i] * kLog2e - mb);
+                const float p = __builtin_amdgcn_exp2f(s[kh][i]);
                 lsum += p;
                 pf[kh][i >> 3][i & 7] = (f16)p;
             }
-        // rescale the running sums only when some query of this wave saw a new maximum (alpha == 1 exactly otherwise)
-        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
-            m_run = m_new;
-        }
         l_run += lsum;
 #pragma unroll
         for (int kh = 0; kh < 2; kh++)
@@ -337,8 +347,13 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
         if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
         __syncthreads();
     };
-    for (int kt = 0; kt + 1 < n_tiles; kt++) tile(kt, std::false_type{});
-    if (T & 63) tile(n_tiles - 1, std::true_type{}); else tile(n_tiles - 1, std::false_type{});
+    if (n_tiles == 1) {
+        if (T & 63) tile(0, std::true_type{}, std::true_type{}); else tile(0, std::false_type{}, std::true_type{});
+    } else {
+        tile(0, std::false_type{}, std::true_type{});
+        for (int kt = 1; kt + 1 < n_tiles; kt++) tile(kt, std::false_type{}, std::false_type{});
+        if (T & 63) tile(n_tiles - 1, std::true_type{}, std::false_type{}); else tile(n_tiles - 1, std::false_type{}, std::false_type{});
+    }
     // normalise, stage the [128 q][64 dh] tile in LDS, store whole rows
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;

@@ -109,14 +109,14 @@ struct EpiConv2 {          // rows have period T+1; x[b*T+t][n] = gelu(acc+b) + 
     }
 };
 
-struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -> K[b][h][t][64]; [2d,3d): V -> Vt[b][h][64][Tp]
+struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d): K -> K[b][h][t][64]; [2d,3d): V -> Vt[b][h][64][Tp]
     static constexpr bool kWide = true;
     f16 *Q, *K, *Vt; const float *bias; int d, H, T, Tp;
     int b0 = 0, base = 0;                   // begin_tile: utterance of the tile's first row, and that utterance's first row
     __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = m0 / T; base = b0 * T; }
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
-        if (n < d) a *= 0.125f;
+        if (n < d) a *= kEncQScale;
         return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
     __device__ __forceinline__ bool wide(int n) const { return n < 2 * d; }      // the V part is stored transposed, element by element
@@ -132,7 +132,7 @@ struct EpiEncQKV {         // n in [0,d): Q*(1/8) -> Q[b][h][t][64]; [d,2d): K -
         const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
         const int part = n / d, c = n - part * d, h = c >> 6, e = c & 63;
         if (part == 0) {
-            f16x4 o = {(f16)(a[0] * 0.125f), (f16)(a[1] * 0.125f), (f16)(a[2] * 0.125f), (f16)(a[3] * 0.125f)};
+            f16x4 o = {(f16)(a[0] * kEncQScale), (f16)(a[1] * kEncQScale), (f16)(a[2] * kEncQScale), (f16)(a[3] * kEncQScale)};
             *(f16x4 *)(Q + (((long)b * H + h) * Tp + t) * 64 + e) = o;
         } else if (part == 1) {
             f16x4 o = {(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};

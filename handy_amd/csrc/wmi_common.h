@@ -21,6 +21,9 @@ constexpr int kHop = 160;
 constexpr int kChunkSec = 30;
 constexpr int kNBins = 201;
 constexpr int kHeadDim = 64;          // every Whisper size uses 64-wide heads
+// The encoder stores Q times log2(e)/8: 1/sqrt(64) of the attention and the base change of its exponentials in one
+// fp16 rounding, so that K Q^T is the score in log2 units (the decoder's Q carries the exact 1/8 only).
+constexpr float kEncQScale = 0.125f * 1.4426950408889634f;
 constexpr int kPageTokens = 16;       // self-attention KV page
 constexpr int kMaxTextCtx = 448;
 constexpr int kMaxPagesPerSeq = kMaxTextCtx / kPageTokens;
