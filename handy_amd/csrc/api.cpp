@@ -497,6 +497,36 @@ int wmi_debug_quant_rows(int ggml_type, const void *blocks, int N, int K, const 
     WMI_CATCH(-1)
 }
 
+// Test hook: softmax_2(q k^T) v through enc_attention_kernel. Host layout [B][H][T][64] for q, k, v; the device gets Q, K padded
+// to Tp rows and V transposed ([B][H][64][Tp]), the padding zero, as the QKV GEMM epilogues leave them.
+int wmi_debug_enc_attention(int B, int H, int T, const unsigned short *q, const unsigned short *k, const unsigned short *v, unsigned short *out) {
+    WMI_TRY
+    if (B <= 0 || H <= 0 || T <= 0 || T > 4096 || !q || !k || !v || !out) return -1;
+    const int Tp = round_up(T, 128);
+    const size_t n_pad = (size_t)B * H * Tp * 64, n_out = (size_t)B * T * H * 64;
+    std::vector<unsigned short> hq(n_pad, 0), hk(n_pad, 0), hvt(n_pad, 0);
+    for (size_t bh = 0; bh < (size_t)B * H; bh++)
+        for (int t = 0; t < T; t++)
+            for (int e = 0; e < 64; e++) {
+                const size_t src = (bh * T + t) * 64 + e;
+                hq[(bh * Tp + t) * 64 + e] = q[src];
+                hk[(bh * Tp + t) * 64 + e] = k[src];
+                hvt[(bh * 64 + e) * Tp + t] = v[src];
+            }
+    f16 *dq = nullptr, *dk = nullptr, *dvt = nullptr, *datt = nullptr;
+    int rc = -1;
+    if (hipMalloc(&dq, n_pad * 2) == hipSuccess && hipMalloc(&dk, n_pad * 2) == hipSuccess && hipMalloc(&dvt, n_pad * 2) == hipSuccess &&
+        hipMalloc(&datt, n_out * 2 + 256) == hipSuccess &&
+        hipMemcpy(dq, hq.data(), n_pad * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dk, hk.data(), n_pad * 2, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dvt, hvt.data(), n_pad * 2, hipMemcpyHostToDevice) == hipSuccess &&
+        wmi::enc_attention(dq, dk, dvt, datt, B, H, T, Tp, nullptr) && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(out, datt, n_out * 2, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = 0;
+    for (void *p : {(void *)dq, (void *)dk, (void *)dvt, (void *)datt}) (void)hipFree(p);
+    return rc;
+    WMI_CATCH(-1)
+}
+
 #ifdef WMI_HARNESS       // benchmark harness entry points (libwhisper_mi355_harness.so only)
 int wmi_debug_read_gemm_stamps(unsigned long long *out, int n) { return wmi::gemm_read_stamps(out, n) ? 0 : -1; }
 void wmi_debug_set_tile_group(int rows) { if (rows >= 1) wmi::g_tile_group_rows = rows; }

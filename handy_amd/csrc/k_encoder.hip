@@ -269,42 +269,68 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     __syncthreads();
     // One key tile. Q carries log2(e)/8, so K Q^T is the score in log2 units, and the accumulators start at -m_run: the
     // MFMAs leave s - m_run, the exponent's argument, with no further arithmetic. The reference m_run is the maximum of
-    // tile 0 and moves only when a later tile's maximum exceeds it by more than kDefer (then p <= 2^kDefer = 256: fp16
-    // holds that at full relative precision and the sums are fp32, so the result is the same softmax, rounded alike).
+    // tile 0. Later tiles exponentiate straight away and look at the sum afterwards: while a lane's 32 values add up to less
+    // than kRedo = 2^15, each of them is below 2^15 -- fp16 holds that at full relative precision (its maximum is 65504) and
+    // the sums are fp32, so the result is the same softmax, rounded alike. Only when some query of the wave exceeds that does
+    // the wave compute the tile's scores again, move the reference to the new maximum and rescale what it has summed.
     // MASK = the tile holds keys past T (only ever the last one); FIRST = tile 0.
-    constexpr float kDefer = 8.0f;
+    constexpr float kRedo = 32768.0f;
     auto tile = [&](int kt, auto mask_tag, auto first_tag) {
         constexpr bool MASK = decltype(mask_tag)::value, FIRST = decltype(first_tag)::value;
         const char *kb = smem + (kt & 1) * 16384, *vb = kb + 8192;
         if (kt + 1 < n_tiles) load_tile(kt + 1);
         f32x16 s[2];
+        auto scores = [&]() {
 #pragma unroll
-        for (int kh = 0; kh < 2; kh++) {
-            const int row = kh * 32 + r, sw = (row >> 1) & 7;
+            for (int kh = 0; kh < 2; kh++) {
+                const int row = kh * 32 + r, sw = (row >> 1) & 7;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const f16x8 kf = *(const f16x8 *)(kb + row * 128 + (((2 * ks + h) ^ sw) << 4));
-                if (ks == 0) s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], minit, 0, 0, 0);
-                else s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kh], 0, 0, 0);
+                for (int ks = 0; ks < 4; ks++) {
+                    const f16x8 kf = *(const f16x8 *)(kb + row * 128 + (((2 * ks + h) ^ sw) << 4));
+                    if (ks == 0) s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], minit, 0, 0, 0);
+                    else s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kh], 0, 0, 0);
+                }
             }
-        }
-        if (MASK) {
+            if (MASK) {
+#pragma unroll
+                for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int key = kt * 64 + kh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key >= T) s[kh][i] = -INFINITY;
+                    }
+            }
+        };
+        float lsum;
+        f16x8 pf[2][2];
+        auto exponentials = [&]() {
+            lsum = 0.0f;
 #pragma unroll
             for (int kh = 0; kh < 2; kh++)
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    const int key = kt * 64 + kh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= T) s[kh][i] = -INFINITY;
+                    const float p = __builtin_amdgcn_exp2f(s[kh][i]);
+                    lsum += p;
+                    pf[kh][i >> 3][i & 7] = (f16)p;
                 }
+        };
+        scores();
+        bool move = FIRST;
+        if (!FIRST) {
+            exponentials();
+            move = __builtin_amdgcn_ballot_w64(lsum >= kRedo) != 0;          // wave-uniform
+            if (move) {
+                asm volatile("" ::: "memory");                                // a second read of the tile, not 32 more live registers
+                scores();
+            }
         }
-        float mx = -INFINITY;
+        if (move) {
+            float mx = -INFINITY;
 #pragma unroll
-        for (int kh = 0; kh < 2; kh++)
+            for (int kh = 0; kh < 2; kh++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[kh][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // move the reference (wave-uniform branch): always at tile 0, later only past the deferral threshold
-        if (FIRST || __builtin_amdgcn_ballot_w64(mx > kDefer) != 0) {
+                for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[kh][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float delta = FIRST ? mx : fmaxf(mx, 0.0f);      // queries whose maximum did not grow keep theirs (alpha == 1)
 #pragma unroll
             for (int kh = 0; kh < 2; kh++)
@@ -319,17 +345,8 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
 #pragma unroll
                 for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
             }
+            exponentials();
         }
-        float lsum = 0.0f;
-        f16x8 pf[2][2];
-#pragma unroll
-        for (int kh = 0; kh < 2; kh++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const float p = __builtin_amdgcn_exp2f(s[kh][i]);
-                lsum += p;
-                pf[kh][i >> 3][i & 7] = (f16)p;
-            }
         l_run += lsum;
 #pragma unroll
         for (int kh = 0; kh < 2; kh++)

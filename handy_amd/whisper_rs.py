@@ -124,7 +124,7 @@ whisper_full_get_token_data whisper_full_get_token_data_from_state whisper_full_
 wmi_init_state_batch wmi_full_batch wmi_batch_n_utts wmi_batch_n_segments wmi_batch_segment_t0 wmi_batch_segment_t1
 wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks wmi_batch_rc
 wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_pcm_to_mel_device_noalloc wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
-wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_debug_quant_rows wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_set_quant_decode wmi_set_quant_resident wmi_set_decoder_lanes wmi_version
+wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_debug_quant_rows wmi_debug_enc_attention wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_set_quant_decode wmi_set_quant_resident wmi_set_decoder_lanes wmi_version
 wmi_ingest_n_frames wmi_ingest_resample wmi_ingest_gate_plan wmi_ingest_gather
 """.split()
 

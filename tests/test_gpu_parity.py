@@ -70,6 +70,50 @@ def test_gelu_epilogue_over_every_f16_input(wr, M):
     assert not out[:, n_per:64].any() and not out[:, 64:].any()              # gelu(0) = 0 everywhere else
 
 
+@pytest.mark.parametrize("T", [1500, 100, 40, 64, 192])
+@pytest.mark.parametrize("shape", ["random", "rising", "spike", "falling", "low_start"])
+def test_encoder_attention_kernel_against_float64_softmax(wr, T, shape):
+    """enc_attention_kernel on score profiles that move its reference exponent: the kernel takes tile 0's maximum as the
+    reference and moves it only when a later 64-key tile exceeds it by a margin, so bounded random data never leaves the
+    fast path. `rising` climbs ~90 log2 units over the keys (many moves), `spike` puts one key 40 units above the rest late in
+    the sequence, `falling` makes everything after tile 0 underflow, `low_start` starts 50 units below the rest. Reference:
+    softmax base 2 in float64 on the fp16 inputs; the kernel rounds p to fp16 before the PV product: 2^-11 relative."""
+    import ctypes as C
+    L = wr.load_library()
+    L.wmi_debug_enc_attention.restype = C.c_int
+    L.wmi_debug_enc_attention.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    B, H = 2, 3
+    rng = np.random.default_rng(T * 10 + len(shape))
+    q = rng.standard_normal((B, H, T, 64)) * 0.35
+    k = rng.standard_normal((B, H, T, 64)) * 0.7
+    v = rng.standard_normal((B, H, T, 64))
+    u = np.zeros(64); u[:8] = 1.0                                          # q.u = 8 a, k.u = 8 c: an additive score a*c*8
+    j = np.arange(T)[None, None, :, None] / max(T - 1, 1)
+    qa = 1.0 + 0.5 * (np.arange(T) % 5)[None, None, :, None]               # queries of one wave differ in how hard they are hit
+    if shape != "random":
+        q[..., :8] = qa * 0.5
+    if shape == "rising":
+        k[..., :8] = j * 7.5
+    elif shape == "spike":
+        k[..., :8] = 0.0; k[:, :, (2 * T) // 3, :8] = 4.0
+    elif shape == "falling":
+        k[..., :8] = -10.0 * (np.arange(T)[None, None, :, None] >= 64); k[:, :, :64, :8] = 0.0
+    elif shape == "low_start":
+        k[..., :8] = 0.0; k[:, :, :min(64, T // 2), :8] = -6.0
+    q16, k16, v16 = (np.ascontiguousarray(x.astype(np.float16)) for x in (q, k, v))
+    out = np.empty((B, T, H * 64), np.uint16)
+    assert L.wmi_debug_enc_attention(B, H, T, q16.ctypes.data_as(C.c_void_p), k16.ctypes.data_as(C.c_void_p),
+                                     v16.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    s = np.einsum("bhqd,bhkd->bhqk", q16.astype(np.float64), k16.astype(np.float64))
+    p = np.exp2(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhqk,bhkd->bqhd", p, v16.astype(np.float64)).reshape(B, T, H * 64)
+    got = out.view(np.float16).astype(np.float64)
+    assert np.isfinite(got).all()
+    span = float(s.max() - s.min())
+    err = float(np.abs(got - ref).max())
+    assert err <= 4e-3, (shape, T, err, span)                              # observed <= 2e-3 at |v| <= 4.5: twice that
+
+
 @pytest.mark.parametrize("name", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0"])
 def test_few_row_gemm_on_blocks_equals_gemm_on_their_expansion(wr, name):
     """The few-row decoder GEMM reading a weight matrix as ggml blocks (expanded in registers) against the same kernel reading
