@@ -498,7 +498,7 @@ int wmi_debug_quant_rows(int ggml_type, const void *blocks, int N, int K, const 
 }
 
 // Test hook: softmax_2(q k^T) v through enc_attention_kernel. Host layout [B][H][T][64] for q, k, v; the device gets Q, K padded
-// to Tp rows and V transposed ([B][H][64][Tp]), the padding zero, as the QKV GEMM epilogues leave them.
+// to Tp rows and V transposed ([B][H][64][Tp], keys at enc_vt_pos), the padding zero, as the QKV GEMM epilogues leave them.
 int wmi_debug_enc_attention(int B, int H, int T, const unsigned short *q, const unsigned short *k, const unsigned short *v, unsigned short *out) {
     WMI_TRY
     if (B <= 0 || H <= 0 || T <= 0 || T > 4096 || !q || !k || !v || !out) return -1;
@@ -511,7 +511,7 @@ int wmi_debug_enc_attention(int B, int H, int T, const unsigned short *q, const 
                 const size_t src = (bh * T + t) * 64 + e;
                 hq[(bh * Tp + t) * 64 + e] = q[src];
                 hk[(bh * Tp + t) * 64 + e] = k[src];
-                hvt[(bh * 64 + e) * Tp + t] = v[src];
+                hvt[(bh * 64 + e) * Tp + wmi::enc_vt_pos(t)] = v[src];
             }
     f16 *dq = nullptr, *dk = nullptr, *dvt = nullptr, *datt = nullptr;
     int rc = -1;

@@ -201,19 +201,20 @@ bool layer_norm_variant(int variant, const float *x, const float *w, const float
 // ------------------------------------------------------------------------------------------ attention
 // Non-causal softmax(Q K^T) V over T keys, heads of 64. Q is pre-scaled by log2(e)/8 (kEncQScale): scores in log2 units.
 // Workgroup = 4 waves = 128 query rows of one (utterance, head); each wave owns 32 rows and walks
-// the keys in tiles of 64 staged through LDS (register-staged, double-buffered, XOR-swizzled).
+// the keys in tiles of 64 staged through LDS (LDS-DMA, double-buffered, XOR-swizzled).
 //   S^T = K Q^T      v_mfma_f32_32x32x16_f16, K rows as the A operand: a lane then holds scores of
 //                    ONE query (its column) for 16 keys per 32-key half, so the running max / sum
 //                    are per-lane scalars plus one exchange with the other lane half.
 //   O^T += V^T P^T   P^T is taken straight from the S^T accumulators (converted to fp16) as the B
-//                    operand; V arrives pre-transposed ([dh][key], written that way by the QKV GEMM
-//                    epilogue), read in the k-order the accumulator layout implies.
+//                    operand; V arrives pre-transposed ([dh][enc_vt_pos(key)], written that way by the
+//                    QKV GEMM epilogues), read in the k-order the accumulator layout implies.
 // Bound: MFMA (4*T*T*64 flop per head). The output tile goes through LDS so rows are stored whole.
 
 __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restrict__ Q, const f16 *__restrict__ K, const f16 *__restrict__ Vt,
                                                             f16 *__restrict__ att, int H, int T, int Tp) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];    // per stage: K tile 8 KB + V^T tile 8 KB
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations need no VALU
     // Workgroup ids are dealt round-robin to the 8 XCDs (one private L2 each): give every XCD a contiguous run of
     // logical ids, so that the query blocks of one (utterance, head), which all stream the same K and V, share an L2.
     const int nqb = Tp / 128, nblk = gridDim.x;
@@ -231,32 +232,34 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
 
     const f16 *kg = K + bh * Tp * 64;
     const f16 *vg = Vt + bh * 64 * Tp;
-    const int srow = tid >> 2, sc = (tid & 3) * 2;
-    f16x8 pk[2], pv[2];
-    auto load_tile = [&](int kt) {
-        const f16 *ks = kg + ((long)kt * 64 + srow) * 64 + sc * 8;
-        pk[0] = *(const f16x8 *)ks; pk[1] = *(const f16x8 *)(ks + 8);
-        const f16 *vs = vg + (long)srow * Tp + kt * 64 + sc * 8;
-        pv[0] = *(const f16x8 *)vs; pv[1] = *(const f16x8 *)(vs + 8);
-    };
-    auto store_tile = [&](int buf) {
-        char *kb = smem + buf * 16384, *vb = kb + 8192;
-        const int sw = (srow >> 1) & 7;
-        *(f16x8 *)(kb + srow * 128 + (((sc) ^ sw) << 4)) = pk[0];
-        *(f16x8 *)(kb + srow * 128 + (((sc + 1) ^ sw) << 4)) = pk[1];
-        // V^T tile: the P operand of the PV MFMA holds keys {16s + 4h + b, 16s + 8 + 4h + b} (b < 4) in one fragment, so the two
-        // 4-key chunks that meet there are stored side by side (chunk bits a, h swapped) and come back as ONE 16-byte read
-        const int sv = (srow >> 1) & 7;
+    // Staging by LDS-DMA, 16 bytes a lane: one wave-instruction moves a piece of 8 tile rows x 128 B to consecutive LDS
+    // addresses, so the XOR swizzle of the 16-byte slots is applied on the source side (lane (row, slot) fetches the slot
+    // that belongs there). A stage is 8 pieces of K rows and 8 of V^T rows; wave w moves pieces w and w + 4 of each.
+    // V^T needs no shuffling on the way: the P operand of the PV MFMA holds keys {16s + 4h + b, 16s + 8 + 4h + b} (b < 4) in
+    // one fragment, and enc_vt_pos() already put those two 4-key chunks side by side in global memory.
+    const int srow = lane >> 3, sslot = lane & 7;
+    int koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = (wave + 4 * i) * 8 + srow, src_slot = sslot ^ ((row >> 1) & 7);
+        koff[i] = row * 64 + src_slot * 8;
+        voff[i] = row * Tp + src_slot * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        char *base = smem + buf * 16384 + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const f16x4 lo = {pv[i][0], pv[i][1], pv[i][2], pv[i][3]}, hi = {pv[i][4], pv[i][5], pv[i][6], pv[i][7]};
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                const int c8 = (sc + i) * 2 + hh;                                  // 4-key chunk index = 8kh + 4s + 2a + h
-                const int pi = (c8 & ~3) | ((c8 & 1) << 1) | ((c8 >> 1) & 1);      // -> 8kh + 4s + 2h + a
-                *(f16x4 *)(vb + srow * 128 + ((((pi >> 1) ^ sv) << 1 | (pi & 1)) << 3)) = hh ? hi : lo;
-            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + (long)kt * 4096 + koff[i]),
+                                             (__attribute__((address_space(3))) void *)(base + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + (long)kt * 64 + voff[i]),
+                                             (__attribute__((address_space(3))) void *)(base + 8192 + i * 4096), 16, 0, 0);
         }
+    };
+    // every piece of a stage has landed (each wave waits for its own, the barrier joins them) and every wave is done reading
+    // the other stage
+    auto stage_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
 
     f32x16 o0, o1, minit;                         // minit = -m_run in all 16 elements: the C operand of a tile's first MFMA
@@ -264,9 +267,8 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     for (int i = 0; i < 16; i++) { o0[i] = 0.0f; o1[i] = 0.0f; minit[i] = 0.0f; }
     float m_run = 0.0f, l_run = 0.0f;             // m_run: the query's reference exponent (log2 units), set by tile 0
     const int n_tiles = (T + 63) / 64;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    stage(0, 0);
+    stage_barrier();
     // One key tile. Q carries log2(e)/8, so K Q^T is the score in log2 units, and the accumulators start at -m_run: the
     // MFMAs leave s - m_run, the exponent's argument, with no further arithmetic. The reference m_run is the maximum of
     // tile 0. Later tiles exponentiate straight away and look at the sum afterwards: while a lane's 32 values add up to less
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     auto tile = [&](int kt, auto mask_tag, auto first_tag) {
         constexpr bool MASK = decltype(mask_tag)::value, FIRST = decltype(first_tag)::value;
         const char *kb = smem + (kt & 1) * 16384, *vb = kb + 8192;
-        if (kt + 1 < n_tiles) load_tile(kt + 1);
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
         f32x16 s[2];
         auto scores = [&]() {
 #pragma unroll
@@ -361,8 +363,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
                     else o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][sidx], o1, 0, 0, 0);
                 }
             }
-        if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
-        __syncthreads();
+        stage_barrier();
     };
     if (n_tiles == 1) {
         if (T & 63) tile(0, std::true_type{}, std::true_type{}); else tile(0, std::false_type{}, std::true_type{});

@@ -109,7 +109,7 @@ struct EpiConv2 {          // rows have period T+1; x[b*T+t][n] = gelu(acc+b) + 
     }
 };
 
-struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d): K -> K[b][h][t][64]; [2d,3d): V -> Vt[b][h][64][Tp]
+struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d): K -> K[b][h][t][64]; [2d,3d): V -> Vt[b][h][64][enc_vt_pos(t)]
     static constexpr bool kWide = true;
     f16 *Q, *K, *Vt; const float *bias; int d, H, T, Tp;
     int b0 = 0, base = 0;                   // begin_tile: utterance of the tile's first row, and that utterance's first row
@@ -138,7 +138,7 @@ struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d)
             f16x4 o = {(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
             *(f16x4 *)(K + (((long)b * H + h) * Tp + t) * 64 + e) = o;
         } else {
-            f16 *p = Vt + (((long)b * H + h) * 64 + e) * Tp + t;
+            f16 *p = Vt + (((long)b * H + h) * 64 + e) * Tp + enc_vt_pos(t);
             p[0] = (f16)a[0]; p[Tp] = (f16)a[1]; p[2 * Tp] = (f16)a[2]; p[3 * Tp] = (f16)a[3];
         }
     }
@@ -164,7 +164,7 @@ struct EpiVt {
         if (n >= rows) return;
         int b = b0, t = n - base;
         if (T >= 256) { if (t >= T) { t -= T; b++; } } else { b = n / T; t = n - b * T; }
-        *(f16x4 *)(Vt + (((long)b * H + (m >> 6)) * 64 + (m & 63)) * Tp + t) = o;
+        *(f16x4 *)(Vt + (((long)b * H + (m >> 6)) * 64 + (m & 63)) * Tp + enc_vt_pos(t)) = o;      // t % 4 == 0: a whole 4-key chunk
     }
     __device__ __forceinline__ void store8(int m, int n, f16x8 o) const {
         store4(m, n, f16x4{o[0], o[1], o[2], o[3]});

@@ -93,7 +93,7 @@ bool lds_pattern_bench(int pattern, int do_read, int iters, float *ms_out);   //
 bool layer_norm_variant(int variant, const float *x, const float *w, const float *b, f16 *out16, int M, int d, hipStream_t st);   // LayerNorm A/B
 #endif
 bool layer_norm(const float *x, const float *w, const float *b, f16 *out16, float *out32, int M, int d, const int *gather, hipStream_t st);
-// non-causal attention over T keys (padded to Tp), heads of 64: Q,K [B][H][Tp][64], Vt [B][H][64][Tp] -> att [B*T][H*64]
+// non-causal attention over T keys (padded to Tp), heads of 64: Q,K [B][H][Tp][64], Vt [B][H][64][Tp] with key t at enc_vt_pos(t) -> att [B*T][H*64]
 bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st);
 
 // ---- k_decoder.hip --------------------------------------------------------------------------
