@@ -51,6 +51,18 @@ struct EpiF16 {            // out[m][n] = f16(act((acc + bias) * scale))
         if (gelu) return gelu_f16_dev4(a);
         return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
+    // The staged whole-tile epilogue asks for a column's bias once (col_bias) and names the mode (bit 0: bias, bit 1: GELU) at
+    // compile time, so that its 32 value_b() calls per lane are straight-line code: same arithmetic, same bits as value().
+    static constexpr bool kColBias = true;
+    static constexpr int kModes = 4;
+    __device__ __forceinline__ int mode() const { return (bias ? 1 : 0) | (gelu ? 2 : 0); }
+    __device__ __forceinline__ f32x4 col_bias(int n) const { return bias ? *(const f32x4 *)(bias + n) : f32x4{0, 0, 0, 0}; }
+    template <int MODE> __device__ __forceinline__ f16x4 value_b(int m, int n, f32x4 a, f32x4 b) const {
+        if (MODE & 1) a += b;
+        a *= scale;
+        if (MODE & 2) return gelu_f16_dev4(a);
+        return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+    }
     __device__ __forceinline__ bool wide(int n) const { return true; }
     __device__ __forceinline__ bool wide_block(int n0, int bn) const { return true; }
     __device__ __forceinline__ void store8(int m, int n, f16x8 h) const { *(f16x8 *)(out + (long)m * ldc + n) = h; }
@@ -116,6 +128,15 @@ struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d)
     __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = m0 / T; base = b0 * T; }
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
+        if (n < d) a *= kEncQScale;
+        return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+    }
+    static constexpr bool kColBias = true;
+    static constexpr int kModes = 1;
+    __device__ __forceinline__ int mode() const { return 0; }
+    __device__ __forceinline__ f32x4 col_bias(int n) const { return *(const f32x4 *)(bias + n); }
+    template <int MODE> __device__ __forceinline__ f16x4 value_b(int m, int n, f32x4 a, f32x4 b) const {
+        a += b;
         if (n < d) a *= kEncQScale;
         return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
@@ -194,6 +215,14 @@ struct EpiCrossKV {        // n = (layer*2 + kv)*d + h*64 + e ; out[slot(b)][lay
         const f32x4 bb = *(const f32x4 *)(bias + n); a += bb;
         return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
     }
+    static constexpr bool kColBias = true;
+    static constexpr int kModes = 1;
+    __device__ __forceinline__ int mode() const { return 0; }
+    __device__ __forceinline__ f32x4 col_bias(int n) const { return *(const f32x4 *)(bias + n); }
+    template <int MODE> __device__ __forceinline__ f16x4 value_b(int m, int n, f32x4 a, f32x4 b) const {
+        a += b;
+        return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+    }
     __device__ __forceinline__ bool wide(int n) const { return true; }
     __device__ __forceinline__ bool wide_block(int n0, int bn) const { return true; }
     __device__ __forceinline__ void store8(int m, int n, f16x8 o) const { *(f16x8 *)dest(m, n) = o; }
@@ -225,6 +254,8 @@ struct EpiPartial {        // split-K partial sums: ws[split][m][n] = acc (no bi
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const { *(f32x4 *)(ws + split * split_stride + (long)m * ld + n) = a; }
 };
 
+template <class Epi, class = void> struct has_col_bias { static constexpr bool value = false; };
+template <class Epi> struct has_col_bias<Epi, decltype((void)Epi::kColBias)> { static constexpr bool value = Epi::kColBias; };
 template <class Epi, class = void> struct is_splitk { static constexpr bool value = false; };
 template <class Epi> struct is_splitk<Epi, decltype((void)Epi::kSplitK)> { static constexpr bool value = Epi::kSplitK; };
 // Epilogues that map a row (or column) index to (utterance, frame) offer begin_tile(m0, n0): one integer division per
@@ -327,26 +358,60 @@ struct MapSplit {
 template <class Epi, int XB = 0, class Map = MapBlock>          // XB (harness): 1 = no global stores, 2 = no LDS round trip (stores of the raw pairs, wrong values)
 __device__ __forceinline__ void write_tile_staged(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, Map map, int wave, int lane, char *smem) {
     const int fr = lane & 15, fq = lane >> 4;
+    // a lane's four column groups keep their bias for all eight row tiles: four loads, requested before the barrier
+    f32x4 cb[4];
+    if constexpr (has_col_bias<Epi>::value) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) cb[i] = epi.col_bias(n0 + map.col(i) + fq * 4);
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): my last fragment reads are done
     __builtin_amdgcn_s_barrier();                // ... and everybody else's: the stage buffers are free
+    auto convert = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            const int rx = map.row(j) + fr, ry = rx + 16, cn = map.col(i);
-            union { f16x4 h; unsigned u[2]; } x, y;
-            x.h = epi.value(m0 + rx, n0 + cn + fq * 4, acc[i][j]);
-            y.h = epi.value(m0 + ry, n0 + cn + fq * 4, acc[i][j + 1]);
-            const auto s0 = __builtin_amdgcn_permlane16_swap(x.u[0], y.u[0], false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(x.u[1], y.u[1], false, false);
-            union { f16x8 h; unsigned u[4]; } o;
-            o.u[0] = s0[0]; o.u[1] = s1[0]; o.u[2] = s0[1]; o.u[3] = s1[1];
-            const int row = (fq & 1) ? ry : rx, chunk = (cn >> 3) + (fq >> 1);
-            if (XB & 2) { const int p = i * 4 + j / 2, r2 = p * 16 + wave * 2 + (lane >> 5); if (m0 + r2 < M) epi.store8(m0 + r2, n0 + (lane & 31) * 8, o.h); }
-            else *(f16x8 *)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = o.h;
-        }
+            for (int j = 0; j < 8; j += 2) {
+                const int rx = map.row(j) + fr, ry = rx + 16, cn = map.col(i);
+                union { f16x4 h; unsigned u[2]; } x, y;
+                if constexpr (has_col_bias<Epi>::value) {
+                    x.h = epi.template value_b<MODE>(m0 + rx, n0 + cn + fq * 4, acc[i][j], cb[i]);
+                    y.h = epi.template value_b<MODE>(m0 + ry, n0 + cn + fq * 4, acc[i][j + 1], cb[i]);
+                } else {
+                    x.h = epi.value(m0 + rx, n0 + cn + fq * 4, acc[i][j]);
+                    y.h = epi.value(m0 + ry, n0 + cn + fq * 4, acc[i][j + 1]);
+                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(x.u[0], y.u[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(x.u[1], y.u[1], false, false);
+                union { f16x8 h; unsigned u[4]; } o;
+                o.u[0] = s0[0]; o.u[1] = s1[0]; o.u[2] = s0[1]; o.u[3] = s1[1];
+                const int row = (fq & 1) ? ry : rx, chunk = (cn >> 3) + (fq >> 1);
+                if (XB & 2) { const int p = i * 4 + j / 2, r2 = p * 16 + wave * 2 + (lane >> 5); if (m0 + r2 < M) epi.store8(m0 + r2, n0 + (lane & 31) * 8, o.h); }
+                else *(f16x8 *)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = o.h;
+            }
+    };
+    if constexpr (has_col_bias<Epi>::value) {
+        if constexpr (Epi::kModes == 4) {
+            switch (epi.mode()) {                // wave-uniform: one straight-line body per mode
+                case 0: convert(std::integral_constant<int, 0>{}); break;
+                case 1: convert(std::integral_constant<int, 1>{}); break;
+                case 2: convert(std::integral_constant<int, 2>{}); break;
+                default: convert(std::integral_constant<int, 3>{}); break;
+            }
+        } else convert(std::integral_constant<int, 0>{});
+    } else convert(std::integral_constant<int, 0>{});
     if (XB & 2) return;
     __syncthreads();
+    if (m0 + 256 <= M) {                         // no row of the tile lies past M: straight-line stores
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            const int row = p * 16 + wave * 2 + (lane >> 5), chunk = lane & 31;
+            const f16x8 v = *(const f16x8 *)(smem + row * 512 + ((chunk ^ (row & 7)) << 4));
+            if (XB & 1) asm volatile("" ::"v"(v));
+            else epi.store8(m0 + row, n0 + chunk * 8, v);
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < 16; p++) {
         const int row = p * 16 + wave * 2 + (lane >> 5), chunk = lane & 31;

@@ -2,7 +2,7 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from handy_amd import whisper_rs as wr
-L = wr.load_library(wr.HARNESS_LIB_PATH)      # the benchmark-harness build of the library
+L = wr.load_library(os.environ.get("WMI_HARNESS_LIB_PATH") or wr.HARNESS_LIB_PATH)      # the benchmark-harness build of the library (WMI_HARNESS_LIB_PATH: another build, for A/B runs)
 L.wmi_bench_gemm.restype = C.c_int
 L.wmi_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
 names = {0: "256x128 8w 3st", 1: "256x256 8w 2st", 2: "128x128 4w 3st", 3: "128x128 4w 2st", 4: "256x128 8w 2st", 5: "128x256 8w 3st", 6: "64x64 4w 4st", 7: "128x64 4w 4st", 9: "256x256 spread-dma", 10: "256x128 3st spread", 11: "256x256 no-gload", 12: "256x256 mfma-only", 13: "256x256 no-mfma", 14: "stamped", 15: "256x256 spread first half (shipped)", 22: "loads + MFMA (no LDS reads)", 23: "LDS reads only", 24: "loads only", 25: "loads only, same tile", 26: "full loop, same tile", 27: "buffer_load lds staging", 16: "shipped, bias + GELU epilogue", 31: "shipped, residual epilogue", 50: "8-phase", 54: "8-phase no stagger", 55: "8-phase dma first", 51: "8-phase residual", 52: "8-phase bias + GELU", 30: "skinny split-K (no consumer)"}
