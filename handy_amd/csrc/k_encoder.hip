@@ -199,7 +199,7 @@ bool layer_norm_variant(int variant, const float *x, const float *w, const float
 #endif  // WMI_HARNESS
 
 // ------------------------------------------------------------------------------------------ attention
-// Non-causal softmax(Q K^T) V over T keys, heads of 64. Q is pre-scaled by log2(e)/8 (kEncQScale): scores in log2 units.
+// Non-causal softmax(Q K^T) V over T keys, heads of 64. Q is pre-scaled by 1/8 (kEncQScale, exact in fp16).
 // Workgroup = 4 waves = 128 query rows of one (utterance, head); each wave owns 32 rows and walks
 // the keys in tiles of 64 staged through LDS (LDS-DMA, double-buffered, XOR-swizzled).
 //   S^T = K Q^T      v_mfma_f32_32x32x16_f16, K rows as the A operand: a lane then holds scores of
@@ -209,6 +209,8 @@ bool layer_norm_variant(int variant, const float *x, const float *w, const float
 //                    operand; V arrives pre-transposed ([dh][enc_vt_pos(key)], written that way by the
 //                    QKV GEMM epilogues), read in the k-order the accumulator layout implies.
 // Bound: MFMA (4*T*T*64 flop per head). The output tile goes through LDS so rows are stored whole.
+
+constexpr float kLog2e = 1.4426950408889634f;
 
 __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restrict__ Q, const f16 *__restrict__ K, const f16 *__restrict__ Vt,
                                                             f16 *__restrict__ att, int H, int T, int Tp) {
@@ -265,12 +267,12 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     f32x16 o0, o1, minit;                         // minit = -m_run in all 16 elements: the C operand of a tile's first MFMA
 #pragma unroll
     for (int i = 0; i < 16; i++) { o0[i] = 0.0f; o1[i] = 0.0f; minit[i] = 0.0f; }
-    float m_run = 0.0f, l_run = 0.0f;             // m_run: the query's reference exponent (log2 units), set by tile 0
+    float m_run = 0.0f, l_run = 0.0f;             // m_run: the query's reference score, set by tile 0
     const int n_tiles = (T + 63) / 64;
     stage(0, 0);
     stage_barrier();
-    // One key tile. Q carries log2(e)/8, so K Q^T is the score in log2 units, and the accumulators start at -m_run: the
-    // MFMAs leave s - m_run, the exponent's argument, with no further arithmetic. The reference m_run is the maximum of
+    // One key tile. The accumulators start at -m_run, so the MFMAs leave s - m_run, and p = 2^(log2(e) (s - m_run)) is one
+    // multiply and one exponential per score. The reference m_run is the maximum of
     // tile 0. Later tiles exponentiate straight away and look at the sum afterwards: while a lane's 32 values add up to less
     // than kRedo = 2^15, each of them is below 2^15 -- fp16 holds that at full relative precision (its maximum is 65504) and
     // the sums are fp32, so the result is the same softmax, rounded alike. Only when some query of the wave exceeds that does
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
             for (int kh = 0; kh < 2; kh++)
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    const float p = __builtin_amdgcn_exp2f(s[kh][i]);
+                    const float p = __builtin_amdgcn_exp2f(s[kh][i] * kLog2e);
                     lsum += p;
                     pf[kh][i >> 3][i & 7] = (f16)p;
                 }
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
 #pragma unroll
             for (int i = 0; i < 16; i++) minit[i] = -m_run;
             if (!FIRST) {
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                const float alpha = __builtin_amdgcn_exp2f(-delta * kLog2e);
                 l_run *= alpha;
 #pragma unroll
                 for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }

@@ -21,9 +21,8 @@ constexpr int kHop = 160;
 constexpr int kChunkSec = 30;
 constexpr int kNBins = 201;
 constexpr int kHeadDim = 64;          // every Whisper size uses 64-wide heads
-// The encoder stores Q times log2(e)/8: 1/sqrt(64) of the attention and the base change of its exponentials in one
-// fp16 rounding, so that K Q^T is the score in log2 units (the decoder's Q carries the exact 1/8 only).
-constexpr float kEncQScale = 0.125f * 1.4426950408889634f;
+// 1/sqrt(64), applied to the encoder's Q after its rounding to fp16 (exact): Q and K carry the reference's bits.
+constexpr float kEncQScale = 0.125f;
 // Position of key t in the encoder's transposed V (Vt[b][h][e][.]): within every group of 16 keys the middle two 4-key chunks
 // trade places (bits 2 and 3 of t swap), so that the two chunks one fragment of the attention's P V product needs sit in one
 // 16-byte piece, which the attention kernel's LDS-DMA then moves whole.

@@ -97,7 +97,7 @@ WHISPER_API int wmi_debug_gemm_gelu(int M, int N, int K, const float *A, const f
 WHISPER_API int wmi_debug_expand_blocks(int ggml_type, const void *blocks, long long n_blocks, unsigned short *out);
 WHISPER_API int wmi_debug_quant_rows(int ggml_type, const void *blocks, int N, int K, const unsigned short *a_f16, int rows, float *out_blocks, float *out_f16);   /* test hook: few-row GEMM on blocks vs on their fp16 expansion */
 /* Test hook: the encoder's attention kernel on host buffers. q, k, v: fp16 bit patterns [B][H][T][64], q already in the kernel's
- * units (scores in log2 units: p = 2^(q.k - max)); out: fp16 bit patterns [B][T][H*64]. */
+ * units (the 1/8 applied: p = exp(q.k - max)); out: fp16 bit patterns [B][T][H*64]. */
 WHISPER_API int wmi_debug_enc_attention(int B, int H, int T, const unsigned short *q, const unsigned short *k, const unsigned short *v, unsigned short *out);
 
 #ifdef WMI_HARNESS
