@@ -600,30 +600,37 @@ int wmi_bench_layer_norm(int M, int d, int variant, int iters, float *ms_out) {
     WMI_CATCH(-1)
 }
 
-// Harness: the same random operands through two tile variants; returns the largest |difference| of the fp16 outputs.
+// Harness: the same random operands through two tile variants; returns the largest |difference| of the outputs
+// (fp16, or fp32 when both variants write fp32 rows: 56 and 63).
 int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, int ref_variant, float *max_abs_diff) {
     WMI_TRY
     if (M <= 0 || N % 256 || K % 64 || !max_abs_diff) return -1;
     for (int v : {variant, ref_variant})
-        if (v == 30 || v == 31 || v == 43 || v == 51) return -1;        // these write fp32 rows or split-K partials: more than the f16 output buffer below holds
-    const size_t Mp = round_up(M, 256);
-    std::vector<f16> a(Mp * K), w((size_t)N * K), c0((size_t)M * N), c1((size_t)M * N);
+        if (v == 30 || v == 31 || v == 43 || v == 51 || v == 61) return -1;        // these add to fp32 rows or write split-K partials: nothing to compare through this harness
+    auto is_f32 = [](int v) { return v == 56 || v == 63; };
+    if (is_f32(variant) != is_f32(ref_variant)) return -1;
+    const bool f32 = is_f32(variant);
+    const size_t Mp = round_up(M, 256), esz = f32 ? 4 : 2;
+    std::vector<f16> a(Mp * K), w((size_t)N * K);
+    std::vector<unsigned char> c0((size_t)M * N * esz), c1((size_t)M * N * esz);
     uint32_t x = 777u;
     auto rnd = [&]() { x = x * 1664525u + 1013904223u; return (float)((int)(x >> 9) % 2001 - 1000) * 1e-3f; };
     for (auto &v : a) v = (f16)rnd();
     for (auto &v : w) v = (f16)rnd();
     f16 *da = nullptr, *dw = nullptr, *dc = nullptr;
     int rc = -1;
-    if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess && hipMalloc(&dc, Mp * N * 2 + 4096) == hipSuccess &&
+    if (hipMalloc(&da, a.size() * 2 + 4096) == hipSuccess && hipMalloc(&dw, w.size() * 2 + 4096) == hipSuccess && hipMalloc(&dc, Mp * N * esz + 4096) == hipSuccess &&
         hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
-        hipMemset(dc, 0xff, Mp * N * 2) == hipSuccess &&
+        hipMemset(dc, 0xff, Mp * N * esz) == hipSuccess &&
         gemm_variant(variant, da, K, dw, K, M, N, K, dc, N, nullptr) && hipDeviceSynchronize() == hipSuccess &&
-        hipMemcpy(c0.data(), dc, c0.size() * 2, hipMemcpyDeviceToHost) == hipSuccess && hipMemset(dc, 0xff, Mp * N * 2) == hipSuccess &&
+        hipMemcpy(c0.data(), dc, c0.size(), hipMemcpyDeviceToHost) == hipSuccess && hipMemset(dc, 0xff, Mp * N * esz) == hipSuccess &&
         gemm_variant(ref_variant, da, K, dw, K, M, N, K, dc, N, nullptr) && hipDeviceSynchronize() == hipSuccess &&
-        hipMemcpy(c1.data(), dc, c1.size() * 2, hipMemcpyDeviceToHost) == hipSuccess) {
+        hipMemcpy(c1.data(), dc, c1.size(), hipMemcpyDeviceToHost) == hipSuccess) {
         float d = 0;
-        for (size_t i = 0; i < c0.size(); i++) {
-            const float e = fabsf((float)c0[i] - (float)c1[i]);
+        for (size_t i = 0; i < (size_t)M * N; i++) {
+            const float u = f32 ? ((const float *)c0.data())[i] : (float)((const f16 *)c0.data())[i];
+            const float v = f32 ? ((const float *)c1.data())[i] : (float)((const f16 *)c1.data())[i];
+            const float e = fabsf(u - v);
             d = (e == e) ? fmaxf(d, e) : INFINITY;
         }
         *max_abs_diff = d;

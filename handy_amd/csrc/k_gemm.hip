@@ -44,6 +44,7 @@ __device__ __forceinline__ float gelu_f16_dev(float x) {
 
 struct EpiF16 {            // out[m][n] = f16(act((acc + bias) * scale))
     static constexpr bool kWide = true;
+    static constexpr int kStoresPerTile = 16;
     f16 *out; long ldc; const float *bias; int gelu; float scale;
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         if (bias) { const f32x4 b = *(const f32x4 *)(bias + n); a += b; }
@@ -71,6 +72,7 @@ struct EpiF16 {            // out[m][n] = f16(act((acc + bias) * scale))
 
 struct EpiF32 {            // out[m][n] = acc + bias
     static constexpr bool kWide = false;
+    static constexpr int kStoresPerTile = 32;
     float *out; long ldc; const float *bias;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
         if (bias) { const f32x4 b = *(const f32x4 *)(bias + n); a += b; }
@@ -81,6 +83,7 @@ struct EpiF32 {            // out[m][n] = acc + bias
 struct EpiResidual {       // x[m][n] += acc + bias   (fp32 residual stream, in place)
     static constexpr bool kWide = false;
     static constexpr bool kReadsOutput = true;      // load() early, apply() later: the staged epilogue hides the read's latency
+    static constexpr int kStoresPerTile = 32;
     float *x; long ldc; const float *bias;
     __device__ __forceinline__ f32x4 load(int m, int n) const { return *(const f32x4 *)(x + (long)m * ldc + n); }
     __device__ __forceinline__ void apply(int m, int n, f32x4 a, f32x4 r) const {
@@ -92,6 +95,7 @@ struct EpiResidual {       // x[m][n] += acc + bias   (fp32 residual stream, in 
 
 struct EpiConv1 {          // rows have period P = 2T+2 per utterance; h1[m+1][n] = t < 2T ? gelu(acc+b) : 0
     static constexpr bool kWide = true;
+    static constexpr int kStoresPerTile = 16;
     f16 *h1; int d; const float *bias; int period; int t_valid;
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         const int t = m % period;
@@ -123,6 +127,7 @@ struct EpiConv2 {          // rows have period T+1; x[b*T+t][n] = gelu(acc+b) + 
 
 struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d): K -> K[b][h][t][64]; [2d,3d): V -> Vt[b][h][64][enc_vt_pos(t)]
     static constexpr bool kWide = true;
+    static constexpr int kStoresPerTile = 16;
     f16 *Q, *K, *Vt; const float *bias; int d, H, T, Tp;
     int b0 = 0, base = 0;                   // begin_tile: utterance of the tile's first row, and that utterance's first row
     __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = m0 / T; base = b0 * T; }
@@ -172,6 +177,8 @@ struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d)
 // T % 4 == 0: four consecutive columns never straddle two utterances.
 struct EpiVt {
     static constexpr bool kWide = true;
+    static constexpr int kStoresPerTile = 32;                                              // store8 is two store4
+    __device__ __forceinline__ bool tile_full(int m0, int n0, int M) const { return m0 + 256 <= M && n0 + 256 <= rows; }
     f16 *Vt; const float *bias; int H, T, Tp, rows;
     int b0 = 0, base = 0;                   // begin_tile: utterance of the tile's first column, and that utterance's first column
     __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = n0 / T; base = b0 * T; }
@@ -196,6 +203,7 @@ struct EpiVt {
 
 struct EpiCrossKV {        // n = (layer*2 + kv)*d + h*64 + e ; out[slot(b)][layer][kv][h][t][64]
     static constexpr bool kWide = true;
+    static constexpr int kStoresPerTile = 16;
     f16 *out; const float *bias; const int *slots; int d, H, T, Tp, n_layer;
     int b0 = -1, base = 0, lk0 = 0, nbase = 0;      // begin_tile: utterance / (layer, k|v) of the tile's first row / column
     __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = m0 / T; base = b0 * T; lk0 = n0 / d; nbase = lk0 * d; }
@@ -263,6 +271,14 @@ template <class Epi> struct is_splitk<Epi, decltype((void)Epi::kSplitK)> { stati
 // the compiler's division sequence is ~30 instructions, and the staged epilogue makes 16-32 stores per lane).
 template <class Epi, class = void> struct has_begin_tile { static constexpr bool value = false; };
 template <class Epi> struct has_begin_tile<Epi, decltype((void)&Epi::begin_tile)> { static constexpr bool value = true; };
+// kStoresPerTile: global store instructions one wave issues in the staged epilogue of a tile whose every row (and, where the
+// epilogue looks at columns, column) is in range -- never more than it really issues. The persistent kernel counts them into
+// its first waits of the next tile (vmcnt is in issue order), so that those waits cover the half-tiles they are about and
+// not the acknowledgement of the epilogue's stores as well. 0: unknown, the waits cover everything.
+template <class Epi, class = void> struct stores_per_tile { static constexpr int value = 0; };
+template <class Epi> struct stores_per_tile<Epi, decltype((void)Epi::kStoresPerTile)> { static constexpr int value = Epi::kStoresPerTile; };
+template <class Epi, class = void> struct has_tile_full { static constexpr bool value = false; };
+template <class Epi> struct has_tile_full<Epi, decltype((void)&Epi::tile_full)> { static constexpr bool value = true; };
 template <class Epi, class = void> struct reads_output { static constexpr bool value = false; };
 template <class Epi> struct reads_output<Epi, decltype((void)Epi::kReadsOutput)> { static constexpr bool value = Epi::kReadsOutput; };
 
@@ -486,7 +502,7 @@ template <int MAXS, int LPS> __device__ __forceinline__ void wait_stages(int you
 // groups instead of in one burst after the barrier; kFirstHalf confines that to the first k-half of the step,
 // so the loads get the second half's MFMAs as extra time to land. Harness-only builds: kNoLoads / kNoLdsReads /
 // kNoMfma drop one ingredient of the loop (ablation timing), kStamps records s_memtime per loop section.
-enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128, kNoStagger = 256, kIssueFirst = 512, kVSplit = 1024 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
+enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128, kNoStagger = 256, kIssueFirst = 512, kVSplit = 1024, kOneTile = 2048, kNoRelax = 4096 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
 // kVSplit (product, 64x64 tile): the K loop is cut into slices of `vs` steps whose sums are added in slice order -- the very
 // additions the split-K path makes (one partial per slice, summed by its consumer), so the two paths agree bit for bit.
 
@@ -803,6 +819,341 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const f16 *__restrict__ A
         }
 }
 
+// ------------------------------------------------------------------------------------------ persistent 8-phase kernel
+// The same loop with one workgroup per CU walking a list of tiles (tile ids blockIdx.x, + gridDim.x, ...: the ids one CU
+// would have been handed by a grid of one workgroup per tile, so the L2 grouping of tile_coords is unchanged). What it buys:
+//   * the stream of half-tiles does not stop at a tile boundary. K/64 is even, so the next tile's K-step 0 has the slot
+//     parity the ring expects, and the last six phases of a tile issue the next tile's first six half-tiles into slots
+//     0-5 exactly as they would issue the current tile's; the counted wait stays at four half-tiles in flight. A tile
+//     therefore has no prologue (no cold first loads), and no workgroup has to retire, drain its stores and be
+//     dispatched again between two tiles;
+//   * those loads land while the epilogue runs. The epilogue stages through the 64 KB that are free meanwhile -- ring
+//     slots 6 and 7 (the last K-step's BH / AH, read two and one phases before the loop ends) plus 32 KB above the ring
+//     (LDS is 160 KB) -- in two 128-row halves (f16 results) or four 128 x 128 quarters (fp32 results), with the next
+//     half's conversions (bias, GELU) computed before the barrier that frees the staging area;
+//   * a barrier closes the epilogue: the next tile's phase 0 issues into slot 6.
+// Accumulation order, epilogue arithmetic and results are those of gemm_nt8_kernel.
+template <class Epi, int MODE>
+__device__ __forceinline__ void write_tile_halves(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, MapSplit map, int wave, int lane, char *stg) {
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 cb[4];
+    if constexpr (has_col_bias<Epi>::value) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) cb[i] = epi.col_bias(n0 + map.col(i) + fq * 4);
+    }
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    const bool full = m0 + 256 <= M;
+    f16x8 o[8];
+    auto convert = [&](int hh) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj += 2) {
+                const int j = hh * 4 + jj, rx = map.row(j) + fr, ry = rx + 16, cn = map.col(i);
+                union { f16x4 h; unsigned u[2]; } x, y;
+                if constexpr (has_col_bias<Epi>::value) {
+                    x.h = epi.template value_b<MODE>(m0 + rx, n0 + cn + fq * 4, acc[i][j], cb[i]);
+                    y.h = epi.template value_b<MODE>(m0 + ry, n0 + cn + fq * 4, acc[i][j + 1], cb[i]);
+                } else {
+                    x.h = epi.value(m0 + rx, n0 + cn + fq * 4, acc[i][j]);
+                    y.h = epi.value(m0 + ry, n0 + cn + fq * 4, acc[i][j + 1]);
+                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(x.u[0], y.u[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(x.u[1], y.u[1], false, false);
+                union { f16x8 h; unsigned u[4]; } v;
+                v.u[0] = s0[0]; v.u[1] = s1[0]; v.u[2] = s0[1]; v.u[3] = s1[1];
+                o[i * 2 + (jj >> 1)] = v.h;
+            }
+    };
+    auto put = [&](int hh) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj += 2) {
+                const int rx = (map.row(hh * 4 + jj) & 127) + fr, row = (fq & 1) ? rx + 16 : rx, chunk = (map.col(i) >> 3) + (fq >> 1);
+                *(f16x8 *)(stg + row * 512 + ((chunk ^ (row & 7)) << 4)) = o[i * 2 + (jj >> 1)];
+            }
+    };
+    auto drain = [&](int hh) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int row = p * 16 + wave * 2 + (lane >> 5), chunk = lane & 31, m = m0 + hh * 128 + row;
+            const f16x8 v = *(const f16x8 *)(stg + row * 512 + ((chunk ^ (row & 7)) << 4));
+            if (full || m < M) epi.store8(m, n0 + chunk * 8, v);
+        }
+    };
+    convert(0);
+    lds_barrier();               // every wave has read its last fragments: slots 6 and 7 are free
+    put(0);
+    lds_barrier();
+    drain(0);
+    convert(1);
+    lds_barrier();               // half 0 has left the staging area
+    put(1);
+    lds_barrier();
+    drain(1);
+    lds_barrier();               // ... and half 1: the next tile may issue into slot 6
+}
+
+template <class Epi>
+__device__ __forceinline__ void write_tile_quarters_f32(const Epi &epi, f32x4 (&acc)[4][8], int M, int m0, int n0, MapSplit map, int wave, int lane, char *stg) {
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr bool RMW = reads_output<Epi>::value;
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    f32x4 old[RMW ? 8 : 1];
+    auto request = [&](int pass) {        // quarter `pass`: rows (pass >> 1) * 128.., columns (pass & 1) * 128..
+        if constexpr (RMW) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int m = m0 + (pass >> 1) * 128 + p * 16 + wave * 2 + (lane >> 5);
+                old[p] = f32x4{0, 0, 0, 0};
+                if (m < M) old[p] = epi.load(m, n0 + (pass & 1) * 128 + (lane & 31) * 4);
+            }
+        }
+    };
+    auto put = [&](int pass) {
+        const int hh = pass >> 1, ci = pass & 1;
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int row = (map.row(hh * 4 + jj) & 127) + fr, chunk = ((map.col(ci * 2 + ii) & 127) >> 2) + fq;
+                *(f32x4 *)(stg + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[ci * 2 + ii][hh * 4 + jj];
+            }
+    };
+    auto drain = [&](int pass) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int row = p * 16 + wave * 2 + (lane >> 5), m = m0 + (pass >> 1) * 128 + row, n = n0 + (pass & 1) * 128 + (lane & 31) * 4;
+            const f32x4 v = *(const f32x4 *)(stg + row * 512 + (((lane & 31) ^ (row & 7)) << 4));
+            if (m < M) {
+                if constexpr (RMW) epi.apply(m, n, v, old[p]);
+                else epi(m, n, v);
+            }
+        }
+    };
+    // a quarter's old values are requested as soon as the previous quarter has used the registers: they travel while that
+    // quarter leaves the staging area and this one enters it
+    request(0);
+    lds_barrier();               // slots 6 and 7 are free
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        put(pass);
+        lds_barrier();
+        drain(pass);
+        if (pass < 3) request(pass + 1);
+        lds_barrier();           // after the last quarter: the next tile may issue into slot 6
+    }
+}
+
+template <class Epi, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_nt8p_kernel(const f16 *__restrict__ A, long lda, const f16 *__restrict__ W, long ldw,
+                                                        int M, int N, int K, int gm, Epi epi0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLOT = 128 * 128;                        // bytes of one half-tile
+    char *const stg = smem + 6 * SLOT;                     // the epilogue's 64 KB: slots 6, 7 and the 32 KB above the ring
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nbm = (M + 255) / 256, nbn = N / 256, nblk = nbm * nbn;
+    const int nk = K / BK, total = 4 * nk;                 // nk is even (checked by the launcher)
+    // staging: half-tile = 16 pieces of 8 rows x 128 B; wave w moves pieces w and w + 8 (rows 8w.. and 64 + 8w..), through
+    // buffer_load ... lds: the tile's first row is the descriptor's base, the half-tile and K-step a scalar offset, and a lane
+    // contributes one 32-bit byte offset per operand -- no 64-bit vector arithmetic in the loop and two address registers in all
+    // (with flat global addresses the compiler keeps eight 64-bit pointers alive beside the 128 accumulators, and spills).
+    const int srow = lane >> 3, sslot = lane & 7;
+    const int a_loff = (int)(((wave * 8 + srow) * lda + ((sslot ^ srow) << 3)) * 2);
+    const int w_loff = (int)(((wave * 8 + srow) * ldw + ((sslot ^ srow) << 3)) * 2);
+    int pid = blockIdx.x;                                  // the launcher keeps gridDim.x <= nblk
+    int bm, bn;
+    tile_coords(pid, nbm, nbn, gm, bm, bn);
+    auto descriptor = [](const f16 *p) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0x7fffffff, 0x00020000); };
+    __amdgpu_buffer_rsrc_t rs_a = descriptor(A + (long)bm * 256 * lda), rs_w = descriptor(W + (long)bn * 256 * ldw), rs_an = rs_a, rs_wn = rs_w;
+    // q = 4 * K-step + {0 AL, 1 BL, 2 BH, 3 AH}; next: of the tile after this one
+    auto issue = [&](bool next, int q) {
+        const int kt = q >> 2, h = q & 3;
+        char *dst = smem + (((kt & 1) << 2) + h) * SLOT + wave * 1024;
+        const bool is_a = h == 0 || h == 3;
+        const long ld = is_a ? lda : ldw;
+        const int soff = (int)(((long)(h >= 2 ? 128 : 0) * ld + (long)kt * BK) * 2);
+        const __amdgpu_buffer_rsrc_t rs = is_a ? (next ? rs_an : rs_a) : (next ? rs_wn : rs_w);
+        const int loff = is_a ? a_loff : w_loff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, loff, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + 8192), 16, loff, soff + (int)(128 * ld), 0, 0);
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    const int a_off = (wr * 64 + fr) * 128, b_off = (wc * 32 + fr) * 128;
+    const int c0 = ((fq) ^ (fr & 7)) << 4, c1 = ((4 + fq) ^ (fr & 7)) << 4;
+    f32x4 acc[4][8];
+    f16x8 fa[4][2], fbl[2][2], fbh[2][2];
+    auto read_a = [&](const char *slot) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { fa[j][0] = *(const f16x8 *)(slot + a_off + j * 2048 + c0); fa[j][1] = *(const f16x8 *)(slot + a_off + j * 2048 + c1); }
+    };
+    auto read_b = [&](const char *slot, f16x8 (&fb)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) { fb[i][0] = *(const f16x8 *)(slot + b_off + i * 2048 + c0); fb[i][1] = *(const f16x8 *)(slot + b_off + i * 2048 + c1); }
+    };
+    auto mma = [&](const f16x8 (&fb)[2][2], int ib, int jb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[ib * 2 + i][jb * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[i][ks], fa[j][ks], acc[ib * 2 + i][jb * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // One phase. R: which quarter; MODE 0: issue index p + 6 of the current tile, 1: of the next tile (the stream runs on
+    // across the tile boundary), 2: nothing left to issue; VM: vector-memory instructions that may stay in flight behind the wait
+    // (8 = four half-tiles).
+    // Everything that varies from phase to phase is a compile-time constant: the loop body is straight-line code.
+    auto phase = [&](auto r_tag, auto mode_tag, auto vm_tag, int kt, const char *sb) {
+        constexpr int r = decltype(r_tag)::value, mode = decltype(mode_tag)::value, vm = decltype(vm_tag)::value;
+        if constexpr (r == 0) { read_b(sb + SLOT, fbl); __builtin_amdgcn_sched_barrier(0); read_a(sb); }
+        else if constexpr (r == 1) read_b(sb + 2 * SLOT, fbh);
+        else if constexpr (r == 2) read_a(sb + 3 * SLOT);
+        if constexpr (mode == 0) issue(false, 4 * kt + r + 6);
+        else if constexpr (mode == 1) issue(true, 4 * kt + r + 6 - total);
+        wait_vmcnt<vm>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if constexpr (r == 0) mma(fbl, 0, 0);
+        else if constexpr (r == 1) mma(fbh, 1, 0);
+        else if constexpr (r == 2) mma(fbh, 1, 1);
+        else mma(fbl, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using V8 = std::integral_constant<int, 8>;
+    // behind a full tile's epilogue the queue holds, in order: half-tiles 2-5 of this tile, the epilogue's stores, then what the
+    // phases issue; phase k of K-step 0 needs half-tile k + 2, so everything younger may stay in flight: 8 + the stores
+    constexpr int kEpiStores = (ABL & kNoRelax) ? 0 : stores_per_tile<Epi>::value;
+    using VR = std::integral_constant<int, 8 + kEpiStores>;
+    static_assert(8 + kEpiStores <= 63, "vmcnt is a 6-bit count");
+    bool relaxed = false;                                      // the previous tile's epilogue issued at least kEpiStores stores
+
+    // the first tile's prologue: six half-tiles in flight, the first two landed (total >= 8)
+#pragma unroll
+    for (int q = 0; q < 6; q++) issue(false, q);
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+
+    for (;;) {
+        const int npid = pid + (int)gridDim.x;
+        const bool has_next = npid < nblk;
+        int bm2 = bm, bn2 = bn;
+        if (has_next) tile_coords(npid, nbm, nbn, gm, bm2, bn2);
+        rs_an = descriptor(A + (long)bm2 * 256 * lda); rs_wn = descriptor(W + (long)bn2 * 256 * ldw);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+        if (wr == 1) __builtin_amdgcn_s_barrier();             // waves 4-7 run one barrier behind
+
+        const char *s0 = smem, *s1 = smem + 4 * SLOT;          // slots AL, BL, BH, AH of the even / odd K-steps
+        if (relaxed) { phase(I0{}, I0{}, VR{}, 0, s0); phase(I1{}, I0{}, VR{}, 0, s0); phase(I2{}, I0{}, VR{}, 0, s0); phase(I3{}, I0{}, VR{}, 0, s0); }
+        else { phase(I0{}, I0{}, V8{}, 0, s0); phase(I1{}, I0{}, V8{}, 0, s0); phase(I2{}, I0{}, V8{}, 0, s0); phase(I3{}, I0{}, V8{}, 0, s0); }
+        phase(I0{}, I0{}, V8{}, 1, s1); phase(I1{}, I0{}, V8{}, 1, s1); phase(I2{}, I0{}, V8{}, 1, s1); phase(I3{}, I0{}, V8{}, 1, s1);
+        for (int kt = 2; kt < nk - 2; kt += 2) {               // steady state: index p + 6 is of this tile, four half-tiles stay in flight
+            phase(I0{}, I0{}, V8{}, kt, s0); phase(I1{}, I0{}, V8{}, kt, s0); phase(I2{}, I0{}, V8{}, kt, s0); phase(I3{}, I0{}, V8{}, kt, s0);
+            phase(I0{}, I0{}, V8{}, kt + 1, s1); phase(I1{}, I0{}, V8{}, kt + 1, s1); phase(I2{}, I0{}, V8{}, kt + 1, s1); phase(I3{}, I0{}, V8{}, kt + 1, s1);
+        }
+        phase(I0{}, I0{}, V8{}, nk - 2, s0); phase(I1{}, I0{}, V8{}, nk - 2, s0);
+        // the last six phases issue the next tile's first six half-tiles (after the last tile: this tile's, once more, so that
+        // the code is the same; nobody reads them and the kernel waits for them before it ends)
+        phase(I2{}, I1{}, V8{}, nk - 2, s0); phase(I3{}, I1{}, V8{}, nk - 2, s0);
+        phase(I0{}, I1{}, V8{}, nk - 1, s1); phase(I1{}, I1{}, V8{}, nk - 1, s1); phase(I2{}, I1{}, V8{}, nk - 1, s1); phase(I3{}, I1{}, V8{}, nk - 1, s1);
+        if (wr == 0) __builtin_amdgcn_s_barrier();             // the barrier waves 4-7 passed at the start
+
+        Epi epi = epi0;
+        const int m0 = bm * 256, n0 = bn * 256;
+        if constexpr (has_begin_tile<Epi>::value) epi.begin_tile(m0, n0);
+        // The epilogue's per-lane offsets are recomputed for every tile from opaque copies of the lane and wave numbers: left to
+        // itself the compiler computes them once, before the tile loop, and then has to carry some twenty registers through the
+        // K loop -- into scratch memory, whose reloads wait behind every load and store in flight.
+        int lane_e = lane, wave_e = wave;
+        asm volatile("" : "+v"(lane_e));
+        asm volatile("" : "+s"(wave_e));
+        const int fr = lane_e & 15, fq = lane_e >> 4;
+        const MapSplit map{wave_e >> 2, wave_e & 3};
+        bool done = false;
+        if constexpr (has_tile_full<Epi>::value) relaxed = epi.tile_full(m0, n0, M);
+        else relaxed = m0 + 256 <= M;
+        if constexpr (Epi::kWide) {
+            if (epi.wide_block(n0, 256)) {
+                if constexpr (has_col_bias<Epi>::value && Epi::kModes == 4) {
+                    switch (epi.mode()) {                          // wave-uniform: one straight-line body per mode
+                        case 0: write_tile_halves<Epi, 0>(epi, acc, M, m0, n0, map, wave_e, lane_e, stg); break;
+                        case 1: write_tile_halves<Epi, 1>(epi, acc, M, m0, n0, map, wave_e, lane_e, stg); break;
+                        case 2: write_tile_halves<Epi, 2>(epi, acc, M, m0, n0, map, wave_e, lane_e, stg); break;
+                        default: write_tile_halves<Epi, 3>(epi, acc, M, m0, n0, map, wave_e, lane_e, stg); break;
+                    }
+                } else write_tile_halves<Epi, 0>(epi, acc, M, m0, n0, map, wave_e, lane_e, stg);
+                done = true;
+            }
+        } else if constexpr (!is_splitk<Epi>::value) {
+            write_tile_quarters_f32<Epi>(epi, acc, M, m0, n0, map, wave_e, lane_e, stg);
+            done = true;
+        }
+        if (!done) {
+            relaxed = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int m = m0 + map.row(j) + fr;
+                    if (m < M) epi(m, n0 + map.col(i) + fq * 4, acc[i][j]);
+                }
+        }
+        if (!has_next) break;
+        pid = npid; bm = bm2; bn = bn2; rs_a = rs_an; rs_w = rs_wn;
+    }
+    wait_vmcnt<0>();
+}
+
+// CUs of the current device, rounded down to a multiple of 8 (the tile order assumes workgroup ids p and p + 8 share an XCD)
+static int persistent_grid() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int n = cus[dev].load(std::memory_order_acquire);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 0;
+        n &= ~7;
+        cus[dev].store(n, std::memory_order_release);
+    }
+    return n;
+}
+// tiles per workgroup from which the persistent kernel is used
+static bool persistent_ok(int M, int N, int K) {
+    const int g = persistent_grid();
+    return g > 0 && N % 256 == 0 && K % (2 * BK) == 0 && K >= 4 * BK && (long)((M + 255) / 256) * (N / 256) >= 2L * g;
+}
+
+template <class Epi, int ABL = 0>
+static bool launch8p(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int group_rows = 0) {
+    if (M <= 0) return true;
+    const int g = persistent_grid();
+    if (g <= 0 || N % 256 != 0 || K % (2 * BK) != 0 || K < 4 * BK) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (persistent 8-phase tile)\n", M, N, K); return false; }
+    const int nblk = ((M + 255) / 256) * (N / 256);
+    constexpr size_t lds = 10 * 128 * 128;
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        if (hipFuncSetAttribute((const void *)gemm_nt8p_kernel<Epi, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        attr_set.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    const int nbn = N / 256, gm = group_rows > 0 ? group_rows : g_tile_group_rows > 0 ? g_tile_group_rows : (nbn <= 8 ? 6 : (nbn <= 16 ? 5 : 4));
+    hipLaunchKernelGGL((gemm_nt8p_kernel<Epi, ABL>), dim3((ABL & kOneTile) ? nblk : std::min(nblk, g)), dim3(512), lds, st, A, lda, W, ldw, M, N, K, gm, epi);
+    return hipGetLastError() == hipSuccess;
+}
+
 template <class Epi, int ABL = 0>
 static bool launch8(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int group_rows = 0) {
     if (M <= 0) return true;
@@ -877,6 +1228,13 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 53: return launch8<EpiF16, kStamps>(A, lda, W, ldw, M, N, K, e, st);                              // ... with per-section cycle stamps
         case 54: return launch8<EpiF16, kNoStagger>(A, lda, W, ldw, M, N, K, e, st);                           // ... all eight waves in step
         case 55: return launch8<EpiF16, kIssueFirst>(A, lda, W, ldw, M, N, K, e, st);                          // ... LDS-DMA issued before the fragment reads
+        case 56: return launch8<EpiF32>(A, lda, W, ldw, M, N, K, EpiF32{(float *)out, ldc, nullptr}, st);     // fp32 rows (out must hold M x N floats)
+        case 60: return launch8p<EpiF16>(A, lda, W, ldw, M, N, K, e, st);                                      // persistent 8-phase kernel, plain f16 epilogue
+        case 61: return launch8p<EpiResidual>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);
+        case 62: return launch8p<EpiF16>(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, (const float *)W, 1, 1.0f}, st);  // bias + GELU
+        case 65: return launch8p<EpiF16, kNoRelax>(A, lda, W, ldw, M, N, K, e, st);                            // ... its first waits of a tile also covering the epilogue's stores
+        case 64: return launch8p<EpiF16, kOneTile>(A, lda, W, ldw, M, N, K, e, st);                            // the persistent kernel's loop, one tile per workgroup
+        case 63: return launch8p<EpiF32>(A, lda, W, ldw, M, N, K, EpiF32{(float *)out, ldc, nullptr}, st);    // fp32 rows
         case 51: return launch8<EpiResidual>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);
         case 52: return launch8<EpiF16>(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, (const float *)W, 1, 1.0f}, st);   // bias + GELU
         case 2: return launch<128, 128, 2, 2, 3, EpiF16>(A, lda, W, ldw, M, N, K, e, st);

@@ -3,6 +3,7 @@
 // Q5_0 variants). Quantised tensors are expanded to fp16 once, at load time: the large matrices on the device from
 // their uploaded blocks (k_load.hip), the few small vectors on the host.
 #include "model.h"
+#include "model_parse.h"
 #include <atomic>
 
 #include <math.h>
@@ -26,92 +27,12 @@ bool quant_resident() {
 }
 
 
-static const char *k_lang[kNumLangs][2] = {
-    {"en", "english"}, {"zh", "chinese"}, {"de", "german"}, {"es", "spanish"}, {"ru", "russian"}, {"ko", "korean"}, {"fr", "french"},
-    {"ja", "japanese"}, {"pt", "portuguese"}, {"tr", "turkish"}, {"pl", "polish"}, {"ca", "catalan"}, {"nl", "dutch"}, {"ar", "arabic"},
-    {"sv", "swedish"}, {"it", "italian"}, {"id", "indonesian"}, {"hi", "hindi"}, {"fi", "finnish"}, {"vi", "vietnamese"}, {"he", "hebrew"},
-    {"uk", "ukrainian"}, {"el", "greek"}, {"ms", "malay"}, {"cs", "czech"}, {"ro", "romanian"}, {"da", "danish"}, {"hu", "hungarian"},
-    {"ta", "tamil"}, {"no", "norwegian"}, {"th", "thai"}, {"ur", "urdu"}, {"hr", "croatian"}, {"bg", "bulgarian"}, {"lt", "lithuanian"},
-    {"la", "latin"}, {"mi", "maori"}, {"ml", "malayalam"}, {"cy", "welsh"}, {"sk", "slovak"}, {"te", "telugu"}, {"fa", "persian"},
-    {"lv", "latvian"}, {"bn", "bengali"}, {"sr", "serbian"}, {"az", "azerbaijani"}, {"sl", "slovenian"}, {"kn", "kannada"},
-    {"et", "estonian"}, {"mk", "macedonian"}, {"br", "breton"}, {"eu", "basque"}, {"is", "icelandic"}, {"hy", "armenian"},
-    {"ne", "nepali"}, {"mn", "mongolian"}, {"bs", "bosnian"}, {"kk", "kazakh"}, {"sq", "albanian"}, {"sw", "swahili"},
-    {"gl", "galician"}, {"mr", "marathi"}, {"pa", "punjabi"}, {"si", "sinhala"}, {"km", "khmer"}, {"sn", "shona"}, {"yo", "yoruba"},
-    {"so", "somali"}, {"af", "afrikaans"}, {"oc", "occitan"}, {"ka", "georgian"}, {"be", "belarusian"}, {"tg", "tajik"},
-    {"sd", "sindhi"}, {"gu", "gujarati"}, {"am", "amharic"}, {"yi", "yiddish"}, {"lo", "lao"}, {"uz", "uzbek"}, {"fo", "faroese"},
-    {"ht", "haitian creole"}, {"ps", "pashto"}, {"tk", "turkmen"}, {"nn", "nynorsk"}, {"mt", "maltese"}, {"sa", "sanskrit"},
-    {"lb", "luxembourgish"}, {"my", "myanmar"}, {"bo", "tibetan"}, {"tl", "tagalog"}, {"mg", "malagasy"}, {"as", "assamese"},
-    {"tt", "tatar"}, {"haw", "hawaiian"}, {"ln", "lingala"}, {"ha", "hausa"}, {"ba", "bashkir"}, {"jw", "javanese"},
-    {"su", "sundanese"}, {"yue", "cantonese"}};
-
-int lang_id_from_str(const char *s) {
-    if (!s) return -1;
-    for (int i = 0; i < kNumLangs; i++)
-        if (!strcmp(s, k_lang[i][0]) || !strcmp(s, k_lang[i][1])) return i;
-    return -1;
-}
-const char *lang_str(int id) { return id >= 0 && id < kNumLangs ? k_lang[id][0] : nullptr; }
-const char *lang_str_full(int id) { return id >= 0 && id < kNumLangs ? k_lang[id][1] : nullptr; }
-
 static const char *k_non_speech[] = {"\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~",
                                      "\xe3\x80\x8c", "\xe3\x80\x8d", "\xe3\x80\x8e", "\xe3\x80\x8f", "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"",
                                      "((", "))", "(((", ")))", "[[", "]]", "{{", "}}", "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xa9",
                                      "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac", "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};
 
 namespace {
-
-struct TensorRef {
-    int ttype = 0;
-    std::vector<int> ne;
-    const uint8_t *data = nullptr;
-    size_t n = 0;
-};
-
-int block_bytes(int tt) {
-    switch (tt) { case 2: return 18; case 3: return 20; case 6: return 22; case 7: return 24; case 8: return 34; }
-    return 0;
-}
-
-inline float h2f(uint16_t h) { f16 v; memcpy(&v, &h, 2); return (float)v; }
-
-// Expands one tensor to f32. Block formats (32 elements per block; low nibbles are elements 0..15, high 16..31):
-// Q4_0 {f16 d, q[16]} d*(q-8) | Q4_1 {f16 d, f16 m, q[16]} d*q+m | Q5_0 {f16 d, u32 qh, q[16]} d*((q|b<<4)-16)
-// Q5_1 {f16 d, f16 m, u32 qh, q[16]} d*(q|b<<4)+m | Q8_0 {f16 d, i8 q[32]} d*q
-void expand_f32(const TensorRef &t, float *dst) {
-    if (t.ttype == 0) { memcpy(dst, t.data, t.n * 4); return; }
-    if (t.ttype == 1) { const uint16_t *s = (const uint16_t *)t.data; for (size_t i = 0; i < t.n; i++) dst[i] = h2f(s[i]); return; }
-    const int bb = block_bytes(t.ttype), tt = t.ttype;
-    for (size_t b = 0; b < t.n / 32; b++) {
-        const uint8_t *p = t.data + b * bb; float *o = dst + b * 32;
-        uint16_t dh; memcpy(&dh, p, 2); const float d = h2f(dh); float mn = 0; p += 2;
-        if (tt == 3 || tt == 7) { uint16_t mh; memcpy(&mh, p, 2); mn = h2f(mh); p += 2; }
-        if (tt == 8) { for (int j = 0; j < 32; j++) o[j] = (float)((int8_t)p[j]) * d; continue; }
-        uint32_t qh = 0;
-        if (tt == 6 || tt == 7) { memcpy(&qh, p, 4); p += 4; }
-        for (int j = 0; j < 16; j++) {
-            int lo = p[j] & 0x0F, hi = p[j] >> 4;
-            if (tt == 6 || tt == 7) { lo |= ((qh >> j) & 1) << 4; hi |= ((qh >> (j + 16)) & 1) << 4; }
-            if (tt == 2) { o[j] = (lo - 8) * d; o[j + 16] = (hi - 8) * d; }
-            else if (tt == 6) { o[j] = (lo - 16) * d; o[j + 16] = (hi - 16) * d; }
-            else { o[j] = lo * d + mn; o[j + 16] = hi * d + mn; }
-        }
-    }
-}
-
-struct Loader {
-    const uint8_t *p, *end;
-    bool ok = true;
-    template <class T> T rd() {
-        T v{};
-        if (p + sizeof(T) > end) { ok = false; return v; }
-        memcpy(&v, p, sizeof(T)); p += sizeof(T);
-        return v;
-    }
-    const uint8_t *take(size_t n) {
-        if ((size_t)(end - p) < n) { ok = false; return nullptr; }
-        const uint8_t *r = p; p += n; return r;
-    }
-};
 
 struct Uploader {
     Model *m;
@@ -212,87 +133,17 @@ VocabIds Model::vocab_ids() const {
 }
 
 Model *load_model(const uint8_t *data, size_t size, int device) {
-    Loader L{data, data + size};
-    if (L.rd<uint32_t>() != 0x67676d6c || !L.ok) { log_msg(2, "load: bad magic (not a ggml whisper file)\n"); return nullptr; }
+    ParsedFile F;
+    if (!parse_model_file(data, size, F) || !check_model_tensors(F)) return nullptr;
     std::unique_ptr<Model> M(new Model());
     M->device = device;
-    HParams &hp = M->hp;
-    int32_t h[11];
-    for (int i = 0; i < 11; i++) h[i] = L.rd<int32_t>();
-    if (!L.ok) { log_msg(2, "load: truncated header\n"); return nullptr; }
-    hp.n_vocab = h[0]; hp.n_audio_ctx = h[1]; hp.n_audio_state = h[2]; hp.n_audio_head = h[3]; hp.n_audio_layer = h[4];
-    hp.n_text_ctx = h[5]; hp.n_text_state = h[6]; hp.n_text_head = h[7]; hp.n_text_layer = h[8]; hp.n_mels = h[9]; hp.ftype = h[10];
-    const int d = hp.n_audio_state;
-    if (hp.n_vocab < 51864 || hp.n_vocab > 52000 || d <= 0 || d % 64 != 0 || d > 1280 || hp.n_text_state != d || hp.n_audio_head <= 0 ||
-        d / hp.n_audio_head != kHeadDim || hp.n_text_head != hp.n_audio_head || hp.n_mels <= 0 || hp.n_mels > 128 || hp.n_mels % 8 != 0 ||
-        hp.n_text_ctx <= 0 || hp.n_text_ctx > kMaxTextCtx || hp.n_audio_ctx <= 0 || hp.n_audio_ctx > 1500 || hp.n_audio_layer <= 0 ||
-        hp.n_text_layer <= 0 || hp.n_audio_layer > 64 || hp.n_text_layer > 64) {
-        log_msg(2, "load: unsupported hyper-parameters (n_vocab %d n_state %d/%d heads %d mels %d text_ctx %d audio_ctx %d)\n", hp.n_vocab, d,
-                hp.n_text_state, hp.n_audio_head, hp.n_mels, hp.n_text_ctx, hp.n_audio_ctx);
-        return nullptr;
-    }
-    const int n_mel = L.rd<int32_t>(), n_fft = L.rd<int32_t>();
-    if (!L.ok || n_mel != hp.n_mels || n_fft != kNBins) { log_msg(2, "load: bad mel filter table %dx%d\n", n_mel, n_fft); return nullptr; }
-    const float *filt = (const float *)L.take((size_t)n_mel * n_fft * 4);
-    if (!L.ok) { log_msg(2, "load: truncated mel filters\n"); return nullptr; }
-    std::vector<float> filters(filt, filt + (size_t)n_mel * n_fft);
-
-    // vocabulary
+    M->hp = F.hp;
+    M->vocab = std::move(F.vocab);
+    const HParams &hp = M->hp;
     Vocab &V = M->vocab;
-    V.n_vocab = hp.n_vocab;
-    const int n_file = L.rd<int32_t>();
-    if (!L.ok || n_file <= 0 || n_file > hp.n_vocab) { log_msg(2, "load: bad vocabulary size %d\n", n_file); return nullptr; }
-    V.id_to_token.resize(hp.n_vocab);
-    for (int i = 0; i < n_file; i++) {
-        const uint32_t len = L.rd<uint32_t>();
-        const uint8_t *s = L.take(len);
-        if (!L.ok) { log_msg(2, "load: truncated vocabulary\n"); return nullptr; }
-        V.id_to_token[i].assign((const char *)s, len);
-        V.token_to_id[V.id_to_token[i]] = i;
-    }
-    if (V.multilingual()) {
-        V.eot++; V.sot++;
-        const int dt = V.num_languages() - 98;
-        V.translate += dt; V.transcribe += dt; V.solm += dt; V.prev += dt; V.nosp += dt; V.tok_not += dt; V.beg += dt;
-    }
-    for (int i = n_file; i < hp.n_vocab; i++) {
-        std::string w;
-        if (i > V.beg) w = "[_TT_" + std::to_string(i - V.beg) + "]";
-        else if (i == V.eot) w = "[_EOT_]";
-        else if (i == V.sot) w = "[_SOT_]";
-        else if (i == V.translate) w = "[_TRANSLATE_]";
-        else if (i == V.transcribe) w = "[_TRANSCRIBE_]";
-        else if (i == V.solm) w = "[_SOLM_]";
-        else if (i == V.prev) w = "[_PREV_]";
-        else if (i == V.nosp) w = "[_NOSP_]";
-        else if (i == V.tok_not) w = "[_NOT_]";
-        else if (i == V.beg) w = "[_BEG_]";
-        else if (i > V.sot && i <= V.sot + V.num_languages()) w = std::string("[_LANG_") + lang_str(i - V.sot - 1) + "]";
-        else w = "[_extra_token_" + std::to_string(i) + "]";
-        V.id_to_token[i] = w;
-        V.token_to_id[w] = i;
-    }
-    { auto it = V.token_to_id.find(" "); V.space = it == V.token_to_id.end() ? -1 : it->second; }
-
-    // tensor directory
-    std::unordered_map<std::string, TensorRef> T;
-    while (L.p < L.end) {
-        const int n_dims = L.rd<int32_t>(), name_len = L.rd<int32_t>(), tt = L.rd<int32_t>();
-        if (!L.ok || n_dims < 1 || n_dims > 4 || name_len <= 0 || name_len > 128) { log_msg(2, "load: corrupt tensor header\n"); return nullptr; }
-        TensorRef t; t.ttype = tt; t.n = 1;
-        for (int i = 0; i < n_dims; i++) { const int e = L.rd<int32_t>(); if (e <= 0) L.ok = false; t.ne.push_back(e); t.n *= (size_t)e; }
-        const uint8_t *nm = L.take(name_len);
-        if (!L.ok) { log_msg(2, "load: corrupt tensor header\n"); return nullptr; }
-        std::string name((const char *)nm, name_len);
-        size_t nbytes;
-        if (tt == 0) nbytes = t.n * 4;
-        else if (tt == 1) nbytes = t.n * 2;
-        else if (block_bytes(tt) && t.n % 32 == 0) nbytes = t.n / 32 * block_bytes(tt);
-        else { log_msg(2, "load: tensor '%s' has unsupported type %d\n", name.c_str(), tt); return nullptr; }
-        t.data = L.take(nbytes);
-        if (!L.ok) { log_msg(2, "load: file truncated inside tensor '%s'\n", name.c_str()); return nullptr; }
-        T[name] = t;
-    }
+    const int d = hp.n_audio_state, n_mel = hp.n_mels, n_fft = kNBins, n_file = F.n_file_vocab;
+    const std::vector<float> &filters = F.filters;
+    const std::unordered_map<std::string, TensorRef> &T = F.tensors;
     bool missing = false;
     auto need = [&](const std::string &name, size_t n) -> const TensorRef * {
         auto it = T.find(name);

@@ -5,23 +5,9 @@
 #include <vector>
 
 #include "kernels.h"
+#include "model_parse.h"
 
 namespace wmi {
-
-struct HParams {
-    int n_vocab = 0, n_audio_ctx = 0, n_audio_state = 0, n_audio_head = 0, n_audio_layer = 0;
-    int n_text_ctx = 0, n_text_state = 0, n_text_head = 0, n_text_layer = 0, n_mels = 0, ftype = 0;
-};
-
-struct Vocab {
-    int n_vocab = 0;
-    std::vector<std::string> id_to_token;
-    std::unordered_map<std::string, int> token_to_id;
-    int eot = 50256, sot = 50257, translate = 50357, transcribe = 50358, solm = 50359, prev = 50360, nosp = 50361, tok_not = 50362, beg = 50363;
-    int space = -1;
-    bool multilingual() const { return n_vocab >= 51865; }
-    int num_languages() const { return n_vocab - 51765 - (multilingual() ? 1 : 0); }
-};
 
 struct EncLayer {
     float *ln1_w, *ln1_b, *bqkv, *bo, *ln2_w, *ln2_b, *b1, *b2;
@@ -63,10 +49,6 @@ Model *load_model(const uint8_t *data, size_t size, int device);
 void set_quant_resident(bool on);
 bool quant_resident();
 
-int lang_id_from_str(const char *s);
-const char *lang_str(int id);
-const char *lang_str_full(int id);
-constexpr int kNumLangs = 100;
 
 // greedy longest-match tokenizer over the model vocabulary (initial_prompt support)
 std::vector<int> tokenize(const Vocab &v, const std::string &text);

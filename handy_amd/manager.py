@@ -167,7 +167,7 @@ class _HipBatchEngine:
 
     def transcribe_batch(self, audios, params) -> List[str]:
         fp = self._proto._full_params(params)
-        self.state.full_batch(fp, audios)
+        self.state.full_batch(fp, audios, allow_failed=True)      # a failed clip fails only its own caller (below)
         out = []
         for u in range(len(audios)):
             rc = self.state.batch_rc(u)

@@ -100,6 +100,15 @@ class wmi_kernel_stat(C.Structure):
 KERNEL_CLASSES = ["mel", "enc_gemm", "enc_attn", "enc_other", "dec_gemm", "dec_cross_attn", "dec_other"]
 
 # every symbol include/whisper.h and include/wmi.h declare (checked by the CPU test-suite)
+WMI_NODE_MAX_TOKENS = 240
+
+
+class wmi_node_record(C.Structure):
+    """include/wmi.h: one utterance's outcome of a node-level job."""
+    _fields_ = [("utt", C.c_int), ("rc", C.c_int), ("device", C.c_int), ("lang_id", C.c_int), ("n_segments", C.c_int), ("n_tokens", C.c_int),
+                ("t0", C.c_int64), ("t1", C.c_int64), ("tokens", C.c_int32 * WMI_NODE_MAX_TOKENS)]
+
+
 DECLARED_SYMBOLS = """
 whisper_context_default_params whisper_context_default_params_by_ref whisper_init_from_file_with_params
 whisper_init_from_file_with_params_no_state whisper_init_from_buffer_with_params whisper_init_from_buffer_with_params_no_state
@@ -126,6 +135,8 @@ wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id
 wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_pcm_to_mel_device_noalloc wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
 wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_debug_quant_rows wmi_debug_enc_attention wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_set_quant_decode wmi_set_quant_resident wmi_set_decoder_lanes wmi_version
 wmi_ingest_n_frames wmi_ingest_resample wmi_ingest_gate_plan wmi_ingest_gather
+wmi_ctx_for_device wmi_node_init wmi_node_free wmi_node_n_devices wmi_node_state wmi_node_context wmi_node_run wmi_node_last_gather
+wmi_node_last_batches wmi_node_run_custom
 """.split()
 
 _lib = None
@@ -420,22 +431,34 @@ class WhisperState:
         if rc != 0: raise WhisperError("GenericError", rc)
         return rc
 
-    def full_batch(self, params: FullParams, pcm_list: Sequence[np.ndarray]) -> int:
+    def _utterance_codes(self, n: int, allow_failed: bool) -> List[int]:
+        """wmi_full_batch returns 0 when the batch ran; an utterance that failed on its own carries its code in wmi_batch_rc.
+        Unless the caller asks for the codes (allow_failed), any failed utterance raises: an empty transcript must not pass
+        for a result."""
+        rcs = [self.L.wmi_batch_rc(self.h, u) for u in range(n)]
+        if not allow_failed:
+            bad = [(u, rc) for u, rc in enumerate(rcs) if rc != 0]
+            if bad:
+                raise WhisperError(f"GenericError: utterance {bad[0][0]} of the batch failed ({len(bad)} in all)", bad[0][1])
+        return rcs
+
+    def full_batch(self, params: FullParams, pcm_list: Sequence[np.ndarray], allow_failed: bool = False) -> List[int]:
+        """whisper_full over a batch of host clips. Returns the per-utterance codes (all 0 unless allow_failed)."""
         arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in pcm_list]
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         ns = (C.c_int * len(arrs))(*[a.size for a in arrs])
         rc = self.L.wmi_full_batch(self.ctx.h, self.h, params.c, ptrs, ns, len(arrs), 0)
         if rc != 0:
             raise WhisperError("GenericError", rc)
-        return rc
+        return self._utterance_codes(len(arrs), allow_failed)
 
-    def full_batch_device(self, params: FullParams, dev_ptrs: Sequence[int], n_samples: Sequence[int]) -> int:
+    def full_batch_device(self, params: FullParams, dev_ptrs: Sequence[int], n_samples: Sequence[int], allow_failed: bool = False) -> List[int]:
         ptrs = (C.c_void_p * len(dev_ptrs))(*dev_ptrs)
         ns = (C.c_int * len(dev_ptrs))(*n_samples)
         rc = self.L.wmi_full_batch(self.ctx.h, self.h, params.c, ptrs, ns, len(dev_ptrs), 1)
         if rc != 0:
             raise WhisperError("GenericError", rc)
-        return rc
+        return self._utterance_codes(len(dev_ptrs), allow_failed)
 
     def full_n_segments(self) -> int: return self.L.whisper_full_n_segments_from_state(self.h)
     def full_lang_id_from_state(self) -> int: return self.L.whisper_full_lang_id_from_state(self.h)

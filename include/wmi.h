@@ -168,6 +168,50 @@ WHISPER_API long long wmi_ingest_gate_plan(const unsigned char *is_voice, long l
 WHISPER_API int wmi_ingest_gather(const float *frames_dev, long long n_frames, const long long *src, long long n_src, float *out_dev,
                                   long long out_cap, long long *n_out, void *stream);
 
+/* ---- Node level: one engine per GPU, data-parallel by utterance -----------------------------------------------------------
+ * No counterpart in the reference (one engine behind one mutex: src-tauri/src/managers/transcription.rs:39, :383; the only
+ * concurrent caller queues on it: src-tauri/src/discord_conversation.rs:470-476). What a bulk driver binds: one process, one
+ * worker thread and one engine (full weights replica) per GPU; the workers pull batches of `batch` utterances from an atomic
+ * counter, so a GPU whose utterances decode for longer pulls fewer; results are fixed-size records in utterance order. With
+ * more than one distinct GPU the records travel to the first device over RCCL point-to-point (librccl is loaded at run time;
+ * WMI_NODE_GATHER=host, a missing library or a refused device list leave them in host memory, where the workers also put
+ * them) -- the only exchange between GPUs; there is no tensor parallelism. */
+WHISPER_API struct whisper_context *wmi_ctx_for_device(const char *path_model, int device);   /* whisper_init_from_file_with_params_no_state on GPU `device` */
+
+#define WMI_NODE_MAX_TOKENS 240
+typedef struct wmi_node_record {
+    int utt;            /* index of the utterance in the job */
+    int rc;             /* 0, or this utterance's whisper_full error code (wmi_batch_rc), or its batch's when the whole batch failed */
+    int device;         /* which of the node's engines ran it (index into the device list) */
+    int lang_id;
+    int n_segments;
+    int n_tokens;       /* tokens of all segments; the first WMI_NODE_MAX_TOKENS are kept (a 30 s window yields at most 224) */
+    int64_t t0, t1;     /* start of the first segment, end of the last (centiseconds) */
+    whisper_token tokens[WMI_NODE_MAX_TOKENS];
+} wmi_node_record;
+typedef struct wmi_node wmi_node;
+
+/* devices == NULL or n_devices == 0: every visible GPU. Engines are created as wmi_init_state_batch(ctx, batch, max_decoders,
+ * enc_chunk). NULL when any engine fails to start. */
+WHISPER_API wmi_node *wmi_node_init(const char *path_model, const int *devices, int n_devices, int batch, int max_decoders, int enc_chunk);
+WHISPER_API void wmi_node_free(wmi_node *node);
+WHISPER_API int wmi_node_n_devices(wmi_node *node);
+WHISPER_API struct whisper_state *wmi_node_state(wmi_node *node, int i);       /* engine i's state, e.g. for wmi_set_force_tokens */
+WHISPER_API struct whisper_context *wmi_node_context(wmi_node *node, int i);
+/* whisper_full semantics for n_utts utterances in HOST memory, spread over the node's engines; records_out[u] describes
+ * utterance u. Callbacks in `params` are called from the worker threads. 0 when the job ran (single utterances and single
+ * batches carry their own codes in the records), -1 bad arguments, -2 a worker died. */
+WHISPER_API int wmi_node_run(wmi_node *node, struct whisper_full_params params, const float *const *samples, const int *n_samples,
+                             int n_utts, wmi_node_record *records_out);
+WHISPER_API int wmi_node_last_gather(wmi_node *node);            /* how the last job's records were gathered: 0 host memory, 1 RCCL */
+WHISPER_API int wmi_node_last_batches(wmi_node *node, int i);    /* batches engine i pulled in the last job */
+/* The same queue with the caller's function in place of the engine call (tests; other engines): fn(user, worker, first, count,
+ * out) fills out[0..count) for utterances first..first+count-1; `utt` and `device` are set by the queue; a non-zero return
+ * marks the whole batch failed with that code. batches_per_worker (may be NULL) receives how many batches each worker pulled. */
+typedef int (*wmi_node_batch_fn)(void *user, int worker, int first, int count, wmi_node_record *out);
+WHISPER_API int wmi_node_run_custom(int n_workers, int n_utts, int batch, wmi_node_batch_fn fn, void *user, wmi_node_record *records_out,
+                                    int *batches_per_worker);
+
 WHISPER_API const char *wmi_version(void);
 
 #ifdef __cplusplus

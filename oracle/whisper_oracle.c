@@ -219,9 +219,11 @@ wo_model *wo_load(const char *path) {
         if (m->n_tensors == cap) { cap = cap ? cap * 2 : 64; m->tensors = (wo_tensor *)realloc(m->tensors, sizeof(wo_tensor) * cap); }
         wo_tensor *t = &m->tensors[m->n_tensors]; memset(t, 0, sizeof *t);
         t->n_dims = n_dims; size_t n = 1;
-        for (int i = 0; i < n_dims; i++) { int32_t e; if (fread(&e, 4, 1, f) != 1) goto fail; t->ne[i] = e; n *= (size_t)e; }
+        for (int i = 0; i < n_dims; i++) { int32_t e; if (fread(&e, 4, 1, f) != 1 || e <= 0 || n > ((size_t)1 << 32) / (size_t)e) goto fail; t->ne[i] = e; n *= (size_t)e; }
         if (fread(t->name, 1, name_len, f) != (size_t)name_len) goto fail;
         t->n = n; t->data = (float *)malloc(sizeof(float) * n);
+        if (!t->data) goto fail;
+        m->n_tensors++;            /* from here on wo_free_model owns the buffer, also when the file ends inside the tensor */
         if (tt == 0) { if (fread(t->data, 4, n, f) != n) goto fail; }
         else if (tt == 1) {
             uint16_t *tmp = (uint16_t *)malloc(2 * n);
@@ -238,7 +240,6 @@ wo_model *wo_load(const char *path) {
             for (size_t i = 0; i < n; i++) t->data[i] = r16(t->data[i]);
             free(tmp);
         }
-        m->n_tensors++;
     }
     fclose(f); f = NULL;
     m->e_pe = find_tensor(m, "encoder.positional_embedding");

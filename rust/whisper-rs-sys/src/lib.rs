@@ -2,7 +2,7 @@
 //! C header. Field order and types MUST stay in lock-step with include/whisper.h: both structs cross
 //! the ABI by value. tests/test_cpu_host.py checks the C side's offsets; `cargo test` here checks sizes.
 #![allow(non_camel_case_types, non_upper_case_globals, non_snake_case)]
-use std::os::raw::{c_char, c_float, c_int, c_void};
+use std::os::raw::{c_char, c_float, c_int, c_uint, c_void};
 
 pub type whisper_token = i32;
 pub type whisper_pos = i32;
@@ -10,6 +10,21 @@ pub type whisper_seq_id = i32;
 
 #[repr(C)] pub struct whisper_context { _private: [u8; 0] }
 #[repr(C)] pub struct whisper_state { _private: [u8; 0] }
+#[repr(C)] pub struct wmi_node { _private: [u8; 0] }
+
+/// include/wmi.h: per-kernel-class device time (HIP events on the engine's stream)
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct wmi_kernel_stat { pub ms: f64, pub work: f64, pub launches: i64 }
+pub const WMI_K_COUNT: usize = 7;
+
+/// include/wmi.h: one utterance's outcome of a node-level job (fixed size: it is what the GPUs exchange)
+pub const WMI_NODE_MAX_TOKENS: usize = 240;
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct wmi_node_record {
+    pub utt: c_int, pub rc: c_int, pub device: c_int, pub lang_id: c_int, pub n_segments: c_int, pub n_tokens: c_int,
+    pub t0: i64, pub t1: i64,
+    pub tokens: [whisper_token; WMI_NODE_MAX_TOKENS],
+}
+pub type wmi_node_batch_fn = Option<unsafe extern "C" fn(*mut c_void, c_int, c_int, c_int, *mut wmi_node_record) -> c_int>;
 
 pub const WHISPER_SAMPLE_RATE: u32 = 16000;
 pub const WHISPER_N_FFT: u32 = 400;
@@ -198,13 +213,71 @@ extern "C" {
 
     // wmi.h: batch extension (no upstream counterpart)
     pub fn wmi_init_state_batch(ctx: *mut whisper_context, max_utts: c_int, max_decoders: c_int, enc_chunk: c_int) -> *mut whisper_state;
+    /// Returns 0 when the batch ran; an utterance that failed on its own carries its code in `wmi_batch_rc` (check it
+    /// for every utterance: a failed one has no segments, which otherwise reads as an empty transcript).
     pub fn wmi_full_batch(ctx: *mut whisper_context, state: *mut whisper_state, params: whisper_full_params, samples: *const *const c_float,
                           n_samples: *const c_int, n_utts: c_int, samples_on_device: c_int) -> c_int;
+    pub fn wmi_batch_n_utts(state: *mut whisper_state) -> c_int;
     pub fn wmi_batch_n_segments(state: *mut whisper_state, utt: c_int) -> c_int;
+    pub fn wmi_batch_segment_t0(state: *mut whisper_state, utt: c_int, seg: c_int) -> i64;
+    pub fn wmi_batch_segment_t1(state: *mut whisper_state, utt: c_int, seg: c_int) -> i64;
+    pub fn wmi_batch_segment_text(state: *mut whisper_state, utt: c_int, seg: c_int) -> *const c_char;
+    pub fn wmi_batch_n_tokens(state: *mut whisper_state, utt: c_int, seg: c_int) -> c_int;
+    pub fn wmi_batch_token_data(state: *mut whisper_state, utt: c_int, seg: c_int, tok: c_int) -> whisper_token_data;
+    pub fn wmi_batch_lang_id(state: *mut whisper_state, utt: c_int) -> c_int;
+    pub fn wmi_batch_rc(state: *mut whisper_state, utt: c_int) -> c_int;
+    pub fn wmi_batch_n_fallbacks(state: *mut whisper_state, utt: c_int) -> c_int;
+    pub fn wmi_set_force_tokens(state: *mut whisper_state, n: c_int);
     /// Remember finished interior 30 s windows between calls (growing recordings: live coaching); 0 = off.
     pub fn wmi_set_window_cache(state: *mut whisper_state, max_windows: c_int);
     pub fn wmi_get_window_cache_stats(state: *mut whisper_state, hits: *mut i64, stores: *mut i64);
-    pub fn wmi_batch_segment_text(state: *mut whisper_state, utt: c_int, seg: c_int) -> *const c_char;
+    pub fn wmi_set_pipeline_groups(state: *mut whisper_state, n: c_int);
+    pub fn wmi_set_encoder_lanes(state: *mut whisper_state, n: c_int) -> c_int;
+    pub fn wmi_set_decoder_lanes(state: *mut whisper_state, n: c_int) -> c_int;
+    pub fn wmi_set_beam_candidates_sampled(state: *mut whisper_state, sampled: c_int);
+    pub fn wmi_set_quant_resident(on: c_int);
+    pub fn wmi_set_quant_decode(state: *mut whisper_state, on: c_int) -> c_int;
+    pub fn wmi_mel_batch_device(ctx: *mut whisper_context, state: *mut whisper_state, pcm_dev: *const c_float, offsets: *const i64,
+                                n_samples: *const c_int, n_utts: c_int) -> c_int;
+    /// The log-mel frontend without any allocation (callers under HIP graph capture, serving loops).
+    pub fn wmi_pcm_to_mel_device_noalloc(ctx: *mut whisper_context, pcm_dev: *const c_float, n_samples: c_int, mel_out_dev: *mut c_float,
+                                         n_frames_out: c_int, stream: *mut c_void) -> c_int;
+    pub fn wmi_version() -> *const c_char;
+
+    // wmi.h: profiling
+    pub fn wmi_set_profiling(state: *mut whisper_state, enabled: c_int);
+    pub fn wmi_set_profiling_classes(state: *mut whisper_state, class_mask: c_uint);
+    pub fn wmi_get_kernel_stats(state: *mut whisper_state, out: *mut wmi_kernel_stat) -> c_int;
+    pub fn wmi_reset_kernel_stats(state: *mut whisper_state);
+    pub fn wmi_get_host_timings(state: *mut whisper_state, out: *mut f64) -> c_int;
+
+    // wmi.h: inspection hooks of the parity tests
+    pub fn wmi_get_mel(state: *mut whisper_state, utt: c_int, out: *mut c_float, n_frames: c_int) -> c_int;
+    pub fn wmi_get_encoder_output(state: *mut whisper_state, out: *mut c_float) -> c_int;
+    pub fn wmi_get_cross_kv(state: *mut whisper_state, layer: c_int, k_out: *mut c_float, v_out: *mut c_float) -> c_int;
+    pub fn wmi_decode_logits_all(ctx: *mut whisper_context, state: *mut whisper_state, tokens: *const whisper_token, n_tokens: c_int,
+                                 n_past: c_int, logits_out: *mut c_float) -> c_int;
+    pub fn wmi_debug_gemm(m: c_int, n: c_int, k: c_int, a: *const c_float, w: *const c_float, c: *mut c_float) -> c_int;
+    pub fn wmi_debug_gemm_gelu(m: c_int, n: c_int, k: c_int, a: *const c_float, w: *const c_float, bias: *const c_float, out: *mut u16) -> c_int;
+    pub fn wmi_debug_expand_blocks(ggml_type: c_int, blocks: *const c_void, n_blocks: i64, out: *mut u16) -> c_int;
+    pub fn wmi_debug_quant_rows(ggml_type: c_int, blocks: *const c_void, n: c_int, k: c_int, a_f16: *const u16, rows: c_int,
+                                out_blocks: *mut c_float, out_f16: *mut c_float) -> c_int;
+    pub fn wmi_debug_enc_attention(b: c_int, h: c_int, t: c_int, q: *const u16, k: *const u16, v: *const u16, out: *mut u16) -> c_int;
+
+    // wmi.h: node level -- one engine per GPU, data-parallel by utterance, result records gathered over RCCL
+    pub fn wmi_ctx_for_device(path_model: *const c_char, device: c_int) -> *mut whisper_context;
+    pub fn wmi_node_init(path_model: *const c_char, devices: *const c_int, n_devices: c_int, batch: c_int, max_decoders: c_int,
+                         enc_chunk: c_int) -> *mut wmi_node;
+    pub fn wmi_node_free(node: *mut wmi_node);
+    pub fn wmi_node_n_devices(node: *mut wmi_node) -> c_int;
+    pub fn wmi_node_state(node: *mut wmi_node, i: c_int) -> *mut whisper_state;
+    pub fn wmi_node_context(node: *mut wmi_node, i: c_int) -> *mut whisper_context;
+    pub fn wmi_node_run(node: *mut wmi_node, params: whisper_full_params, samples: *const *const c_float, n_samples: *const c_int,
+                        n_utts: c_int, records_out: *mut wmi_node_record) -> c_int;
+    pub fn wmi_node_last_gather(node: *mut wmi_node) -> c_int;
+    pub fn wmi_node_last_batches(node: *mut wmi_node, i: c_int) -> c_int;
+    pub fn wmi_node_run_custom(n_workers: c_int, n_utts: c_int, batch: c_int, func: wmi_node_batch_fn, user: *mut c_void,
+                               records_out: *mut wmi_node_record, batches_per_worker: *mut c_int) -> c_int;
 
     // wmi.h: the recorder's resample + VAD gate for bulk files in device memory (audio_toolkit/audio/resampler.rs, vad/smoothed.rs)
     pub fn wmi_ingest_n_frames(in_hz: c_int, n_in: i64) -> i64;
@@ -228,5 +301,7 @@ mod tests {
         assert_eq!(std::mem::size_of::<whisper_token_data>(), 56);
         assert_eq!(std::mem::size_of::<whisper_context_params>(), 48);
         assert_eq!(std::mem::size_of::<whisper_full_params>(), 264);
+        assert_eq!(std::mem::size_of::<wmi_node_record>(), 40 + 4 * WMI_NODE_MAX_TOKENS);
+        assert_eq!(std::mem::size_of::<wmi_kernel_stat>(), 24);
     }
 }

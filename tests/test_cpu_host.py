@@ -50,7 +50,7 @@ def test_struct_layout_matches_the_c_header(tmp_path):
               "language", "detect_language", "suppress_blank", "suppress_nst", "temperature", "no_speech_thold", "greedy", "beam_search",
               "new_segment_callback", "grammar_rules", "grammar_penalty"]
     body = "".join(f'printf("{f} %zu\\n", offsetof(struct whisper_full_params, {f}));\n' for f in fields)
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "whisper.h"\nint main(void){\n'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "wmi.h"\nint main(void){\n'
                    'printf("full %zu\\nctx %zu\\ntok %zu\\n", sizeof(struct whisper_full_params), sizeof(struct whisper_context_params), sizeof(whisper_token_data));\n'
                    + body + "return 0;}\n")
     exe = tmp_path / "layout"
@@ -78,13 +78,19 @@ def test_rust_sys_crate_matches_the_c_header(tmp_path):
         if fields:
             structs[m.group(1)] = fields
     scalar = {"bool": (1, 1), "c_int": (4, 4), "i32": (4, 4), "u32": (4, 4), "c_float": (4, 4), "whisper_token": (4, 4),
-              "whisper_sampling_strategy": (4, 4), "whisper_alignment_heads_preset": (4, 4), "i64": (8, 8), "usize": (8, 8)}
+              "whisper_sampling_strategy": (4, 4), "whisper_alignment_heads_preset": (4, 4), "i64": (8, 8), "usize": (8, 8),
+              "f64": (8, 8), "c_uint": (4, 4)}
+    consts = {k: int(v) for k, v in re.findall(r"pub const (\w+): usize = (\d+);", src)}
 
     def size_align(t):
         if t in scalar:
             return scalar[t]
         if t.startswith("*") or t.startswith("Option<") or t.endswith("_callback"):
             return 8, 8
+        arr = re.fullmatch(r"\[(\w+);\s*(\w+)\]", t)
+        if arr:
+            sz, al = size_align(arr.group(1))
+            return sz * (consts[arr.group(2)] if arr.group(2) in consts else int(arr.group(2))), al
         return layout(t)[1:]
 
     def layout(name):
@@ -98,7 +104,8 @@ def test_rust_sys_crate_matches_the_c_header(tmp_path):
         return offs, (off + align - 1) // align * align, align
 
     check = {"whisper_full_params": "struct whisper_full_params", "whisper_context_params": "struct whisper_context_params",
-             "whisper_token_data": "whisper_token_data", "whisper_aheads": "whisper_aheads", "whisper_grammar_element": "whisper_grammar_element"}
+             "whisper_token_data": "whisper_token_data", "whisper_aheads": "whisper_aheads", "whisper_grammar_element": "whisper_grammar_element",
+             "wmi_node_record": "wmi_node_record", "wmi_kernel_stat": "wmi_kernel_stat"}
     assert set(check) <= set(structs), sorted(structs)
     assert len(structs["whisper_full_params"]) >= 50
     lines = []
@@ -107,7 +114,7 @@ def test_rust_sys_crate_matches_the_c_header(tmp_path):
         for f, _ in structs[rs]:
             lines.append(f'printf("{rs} {f} %zu\\n", offsetof({cname}, {f.rstrip("_")}));')
     prog = tmp_path / "rs_layout.c"
-    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "whisper.h"\nint main(void){\n' + "\n".join(lines) + "\nreturn 0;}\n")
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "wmi.h"\nint main(void){\n' + "\n".join(lines) + "\nreturn 0;}\n")
     exe = tmp_path / "rs_layout"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     c = {}
@@ -128,6 +135,79 @@ def test_rust_sys_crate_matches_the_c_header(tmp_path):
     assert len(fns) > 60
     missing = [f for f in fns if not hasattr(lib, f)]
     assert not missing, missing
+
+
+def _wmi_header_names():
+    """Every WHISPER_API function of include/wmi.h outside the benchmark-harness block."""
+    h = open(os.path.join(ROOT, "include", "wmi.h")).read()
+    h = re.sub(r"#ifdef WMI_HARNESS.*?#endif", "", h, flags=re.S)
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return re.findall(r"WHISPER_API\s+[^;(]*?\b(\w+)\s*\(", h)
+
+
+def test_every_wmi_entry_point_is_bound_everywhere():
+    """A function declared in include/wmi.h that the Rust sys crate or the Python mirror does not know is a function their
+    callers cannot reach -- wmi_batch_rc was one, and without it a failed utterance read as an empty transcript."""
+    from handy_amd import whisper_rs as wr
+    names = _wmi_header_names()
+    assert len(names) > 45 and "wmi_batch_rc" in names and "wmi_node_run" in names, names
+    src = open(os.path.join(ROOT, "rust", "whisper-rs-sys", "src", "lib.rs")).read()
+    rust = set(re.findall(r"pub fn (\w+)\s*\(", src))
+    assert not [n for n in names if n not in rust], [n for n in names if n not in rust]
+    assert not [n for n in names if n not in wr.DECLARED_SYMBOLS], [n for n in names if n not in wr.DECLARED_SYMBOLS]
+    lib = C.CDLL(wr.LIB_PATH)
+    assert not [n for n in names if not hasattr(lib, n)]
+
+
+def test_node_queue_hands_out_every_batch_once():
+    """The node driver's queue with the engine call stubbed (wmi_node_run_custom): worker threads pull batches from one
+    atomic counter; every utterance gets exactly one record, in utterance order, whichever worker ran it; a failing batch
+    marks its own records and the job goes on; a slow worker pulls fewer batches."""
+    import threading
+    import time
+    from handy_amd import whisper_rs as wr
+    lib = C.CDLL(wr.LIB_PATH)
+    rec_t = wr.wmi_node_record
+    fn_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(rec_t))
+    lib.wmi_node_run_custom.restype = C.c_int
+    lib.wmi_node_run_custom.argtypes = [C.c_int, C.c_int, C.c_int, fn_t, C.c_void_p, C.POINTER(rec_t), C.POINTER(C.c_int)]
+    seen, lock = [], threading.Lock()
+
+    def batch(user, worker, first, count, out):
+        if worker == 0:
+            time.sleep(0.02)                       # the slow GPU
+        with lock:
+            seen.append((worker, first, count))
+        if first == 40:
+            return 7                               # this batch fails as a whole
+        for i in range(count):
+            out[i].n_tokens = 3
+            out[i].n_segments = 1
+            out[i].lang_id = worker
+            for k in range(3):
+                out[i].tokens[k] = 1000 * (first + i) + k
+            if first + i == 13:
+                out[i].rc = -3                     # one utterance fails on its own
+        return 0
+
+    n_utts, bsz, n_workers = 103, 8, 4
+    recs = (rec_t * n_utts)()
+    per = (C.c_int * n_workers)()
+    assert lib.wmi_node_run_custom(n_workers, n_utts, bsz, fn_t(batch), None, recs, per) == 0
+    assert sorted(f for _, f, _ in seen) == list(range(0, n_utts, bsz)) and sum(c for _, _, c in seen) == n_utts
+    assert sum(per) == len(seen) == 13 and per[0] < max(per)
+    by_first = {f: w for w, f, _ in seen}
+    for u in range(n_utts):
+        r = recs[u]
+        assert r.utt == u and r.device == by_first[u // bsz * bsz]
+        if 40 <= u < 48:
+            assert r.rc == 7 and r.n_tokens == 0
+        else:
+            assert r.rc == (-3 if u == 13 else 0) and list(r.tokens[:3]) == [1000 * u, 1000 * u + 1, 1000 * u + 2] and r.lang_id == r.device
+    # degenerate jobs
+    assert lib.wmi_node_run_custom(2, 0, 4, fn_t(batch), None, None, None) == 0
+    assert lib.wmi_node_run_custom(0, 5, 4, fn_t(batch), None, recs, None) == -1
+    assert lib.wmi_node_run_custom(2, 5, 0, fn_t(batch), None, recs, None) == -1
 
 
 def test_missing_library_fails_loudly(tmp_path):

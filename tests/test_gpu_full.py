@@ -621,8 +621,10 @@ def test_one_bad_utterance_does_not_fail_the_batch(wr, model_path):
     fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language("auto")
     pcms = [synth_pcm(700, 10 * 16000), synth_pcm(701, 30), synth_pcm(702, 5 * 16000)]
     st = ctx.create_batch_state(3, 1, 2)
-    assert st.full_batch(fp, pcms) == 0
+    assert st.full_batch(fp, pcms, allow_failed=True) == [0, -3, 0]
     assert [st.batch_rc(u) for u in range(3)] == [0, -3, 0]
+    with pytest.raises(wr.WhisperError):          # without the opt-in a failed utterance is an error, not an empty transcript
+        st.full_batch(fp, pcms)
     assert st.batch_tokens(1) == [] and len(st.batch_tokens(0)) > 0 and len(st.batch_tokens(2)) > 0
     one = ctx.create_state()
     for u in (0, 2):
