@@ -53,11 +53,11 @@ CONFIGS = {
     "mel128":        ("micro-v3",       120,       0,     1,    "mel"),
 }
 CLASS_KERNEL = {
-    "enc_gemm": ("mfma", "gemm_nt8_kernel / gemm_nt_kernel (encoder conv, QKV, out, MLP, cross-K/V GEMMs)"),
+    "enc_gemm": ("mfma", "gemm_nt8p_kernel / gemm_nt8_kernel / gemm_nt_kernel (encoder conv, QKV, out, MLP, cross-K/V GEMMs)"),
     "enc_attn": ("mfma", "enc_attention_kernel"),
     "dec_cross_attn": ("hbm", "dec_cross_attention_kernel / dec_cross_attention_mq_kernel (cached encoder K/V streamed once per utterance and layer)"),
     "dec_gemm": ("hbm", "gemm_skinny_kernel / gemm_nt_kernel on decoder rows (decoder weights streamed once per pass)"),
-    "mel": ("hbm", "mel_raw_kernel (PCM in, fp32 log-mel out)"),
+    "mel": ("hbm", "mel_raw_kernel + mel_normalize_batch_kernel (PCM in; clamped, scaled fp32 log-mel out)"),
 }
 
 
@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--strong-total", type=int, default=int(os.environ.get("WMI_STRONG_TOTAL", "10240")),
                     help="headline only: utterances of the fixed strong-scaling job run after the timed steps (0: skip)")
     ap.add_argument("--strong-batch", type=int, default=256, help="utterances per queue entry of the strong-scaling job")
+    ap.add_argument("--result-log", default=os.environ.get("WMI_RESULT_LOG", ""),
+                    help="directory of the strong-scaling job's append-only per-batch result log (default: a directory under the temp dir)")
+    ap.add_argument("--resume", action="store_true", help="strong-scaling job: skip the batches the result log already holds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed step that profiles every kernel class")
     args = ap.parse_args()
@@ -214,7 +217,7 @@ def main():
     gather_dev = dev if args.dist_backend == "nccl" else None
 
     from handy_amd import whisper_rs as wr
-    from handy_amd.node import BatchQueue, gather_ragged_records, gather_token_records, pack_token_records
+    from handy_amd.node import BatchQueue, ResultLog, gather_ragged_records, gather_token_records, pack_token_records
 
     arch, B, tokens, beam, dom = CONFIGS[args.config]
     arch = args.arch or arch
@@ -253,11 +256,12 @@ def main():
         log("engine and inputs ready")
 
     import ctypes as C
+    mel_out = torch.empty((B, ctx.n_mels(), 3000), dtype=torch.float32, device=dev) if mel_only else None
     offs_c = (C.c_longlong * B)(*[i * N_SAMP for i in range(B)]); ns_c = (C.c_int * B)(*ns)
 
     def step(gather=True):
-        if mel_only:
-            assert ctx.L.wmi_mel_batch_device(ctx.h, st.h, C.c_void_p(pcm_dev.data_ptr()), offs_c, ns_c, B) == 0
+        if mel_only:        # the whole frontend: log-mel, per-utterance maximum, clamp and scale into mel_out (the contract's output)
+            assert ctx.L.wmi_mel_batch_device_normalized(ctx.h, st.h, C.c_void_p(pcm_dev.data_ptr()), offs_c, ns_c, B, C.c_void_p(mel_out.data_ptr()), 3000) == 0
             return None
         if host_pcm is not None:
             st.full_batch(fp, host_pcm)
@@ -343,17 +347,29 @@ def main():
         sb = min(args.strong_batch, B)
         n_batches = (args.strong_total + sb - 1) // sb
         queue = BatchQueue(n_batches, name=f"wmi_strong_{args.strong_total}")
+        # every finished batch goes to an append-only log before the next one is pulled: a run that dies late resumes
+        # (--resume) at the first batch the log does not hold instead of starting over
+        import tempfile
+        job_key = f"{arch}-n{args.strong_total}-b{sb}-t{tokens}-beam{beam}"
+        log_dir = args.result_log or os.path.join(tempfile.gettempdir(), f"wmi_result_log_{job_key}")
+        rlog = ResultLog(log_dir, job_key, rank, world, resume=args.resume)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        recs, pulled = [], 0
+        already = rlog.done()
+        recs, pulled = rlog.records(), 0
         for b in queue:
+            if b in already:
+                continue
             u0, u1 = b * sb, min((b + 1) * sb, args.strong_total)
             sel = [(u % B) for u in range(u0, u1)]           # utterance u of the job is clip u mod B of this rank's resident pool
             st.full_batch_device(fp, [ptrs[i] for i in sel], [N_SAMP] * len(sel))
-            recs.append(pack_token_records(range(u0, u1), [st.batch_tokens(k) for k in range(len(sel))], tokens + 2))
+            rec = pack_token_records(range(u0, u1), [st.batch_tokens(k) for k in range(len(sel))], tokens + 2)
+            rlog.append(b, rec)
+            recs.append(rec)
             pulled += 1
+        rlog.close()
         rec = np.concatenate(recs, axis=0) if recs else np.zeros((0, tokens + 4), np.int32)
         allrec = gather_ragged_records(rec, device=gather_dev)
         torch.cuda.synchronize()
@@ -367,7 +383,7 @@ def main():
         if rank == 0:
             assert allrec is not None and allrec[:, 0].tolist() == list(range(args.strong_total)), "strong-scaling job: records missing or duplicated"
             assert int((allrec[:, 1] == tokens + 1).all()), "strong-scaling job: wrong token count"
-            strong = {"utterances": args.strong_total, "batch": sb, "batches": n_batches, "batches_pulled_by_rank0": pulled, "seconds": sdt,
+            strong = {"utterances": args.strong_total, "batch": sb, "batches": n_batches, "batches_pulled_by_rank0": pulled, "batches_taken_from_log": len(already), "result_log": log_dir, "seconds": sdt,
                       "value": 30.0 * args.strong_total / sdt, "unit": "audio-sec/sec", "scaling": "strong",
                       "note": "ranks pull batches from a shared queue (atomic counter on the rendezvous store), token records gathered once at the end"}
             log(f"strong-scaling job: {sdt:.2f} s")
@@ -387,7 +403,8 @@ def main():
         traffic, traffic_src = pmc_traffic() if headline else (None, None)
         if mel_only:
             n_mel = ctx.n_mels()
-            workload = f"log-mel frontend only, {B} x 30 s = {B * 30 / 3600:.2f} h of 16 kHz audio to {n_mel}-bin log-mel (fp32 out), PCM resident in HBM"
+            workload = (f"log-mel frontend only, {B} x 30 s = {B * 30 / 3600:.2f} h of 16 kHz audio to {n_mel}-bin log-mel, clamped to max - 8 per utterance and "
+                        f"scaled ((x + 4) / 4), fp32 [utterance][mel][3000 frames] out, PCM resident in HBM; two kernels per step (raw log-mel + maximum, clamp + scale)")
             metric = f"RTFx (audio-sec/sec), log-mel frontend only, {n_mel} mel bins"
         else:
             workload = (f"Whisper {arch} fp16 (synthetic ggml weights of the exact architecture), {B} different 30 s utterances per GPU per step, "

@@ -79,8 +79,8 @@ struct whisper_context *whisper_init_from_buffer_with_params_no_state(void *buff
     if (!m) return nullptr;
     whisper_context *ctx = new whisper_context();
     ctx->model = m; ctx->params = params; ctx->t_load_ms = now_ms() - t0;
-    // set-up for wmi_pcm_to_mel_device_noalloc on this device (load_model left it current); a failure is reported by
-    // that entry point, which tries once more
+    // set-up for wmi_pcm_to_mel_device_noalloc on this device (load_model left it current); if it fails that entry point
+    // returns -3 on this device
     (void)wmi::mel_noalloc_init(params.gpu_device);
     return ctx;
     WMI_CATCH(nullptr)
@@ -354,6 +354,13 @@ int wmi_mel_batch_device(struct whisper_context *, struct whisper_state *s, cons
     return e->mel_batch_device(pcm_dev, offsets, n, B);
     WMI_CATCH(-1)
 }
+int wmi_mel_batch_device_normalized(struct whisper_context *, struct whisper_state *s, const float *pcm_dev, const long long *offsets, const int *n, int B,
+                                    float *mel_out_dev, int n_frames_out) {
+    WMI_TRY
+    Engine *e = ENG(s); if (!e || !pcm_dev || !offsets || !n || B <= 0 || !mel_out_dev || n_frames_out <= 0 || n_frames_out % 4) return -1;
+    return e->mel_batch_device(pcm_dev, offsets, n, B, mel_out_dev, n_frames_out);
+    WMI_CATCH(-1)
+}
 int wmi_pcm_to_mel_device_noalloc(struct whisper_context *ctx, const float *pcm_dev, int n_samples, float *mel_out_dev, int n_frames_out, void *stream) {
     WMI_TRY
     if (!ctx || !ctx->model) return -1;
@@ -376,6 +383,7 @@ int wmi_get_cross_kv(struct whisper_state *s, int layer, float *k, float *v) {
     Engine *e = ENG(s); return e && k && v ? e->get_cross_kv(layer, k, v) : -1;
     WMI_CATCH(-1)
 }
+void wmi_set_pass_graphs(struct whisper_state *s, int on) { if (Engine *e = ENG(s)) e->set_pass_graphs(on != 0); }
 int wmi_set_decoder_lanes(struct whisper_state *s, int n) {
     Engine *e = ENG(s); if (!e) return -1;
     e->set_decoder_lanes(n);
@@ -526,6 +534,18 @@ int wmi_debug_enc_attention(int B, int H, int T, const unsigned short *q, const 
     return rc;
     WMI_CATCH(-1)
 }
+
+// ------------------------------------------------------------------------------------------ device memory helpers
+void *wmi_dev_alloc(size_t bytes) { void *p = nullptr; return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? p : nullptr; }
+void wmi_dev_free(void *p) { if (p) (void)hipFree(p); }
+int wmi_dev_upload(void *dst, const void *src, size_t bytes) { return !bytes || (dst && src && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1; }
+int wmi_dev_download(void *dst, const void *src, size_t bytes) { return !bytes || (dst && src && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess) ? 0 : -1; }
+int wmi_dev_memset(void *dst, int byte, size_t bytes) { return !bytes || (dst && hipMemset(dst, byte, bytes) == hipSuccess) ? 0 : -1; }
+int wmi_dev_sync(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : -1; }
+long long wmi_dev_free_bytes(void) { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)fr : -1; }
+void *wmi_dev_stream_create(void) { hipStream_t s = nullptr; return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? (void *)s : nullptr; }
+int wmi_dev_stream_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : -1; }
+void wmi_dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
 #ifdef WMI_HARNESS       // benchmark harness entry points (libwhisper_mi355_harness.so only)
 int wmi_debug_read_gemm_stamps(unsigned long long *out, int n) { return wmi::gemm_read_stamps(out, n) ? 0 : -1; }

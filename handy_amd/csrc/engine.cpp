@@ -56,6 +56,7 @@ static size_t split_max_rows() {
 }
 
 Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
+    { const char *e = getenv("WMI_PASS_GRAPHS"); use_graphs_ = !e || atoi(e) != 0; }
     max_utts_ = std::max(1, max_utts);
     max_dec_ = std::min(8, std::max(1, max_dec));
     enc_chunk_ = enc_chunk > 0 ? enc_chunk : 128;        // big chunks: fewer, fuller GEMM launches (about 70 MB of workspace per utterance)
@@ -76,6 +77,7 @@ Engine::Engine(Model *m, int max_utts, int max_dec, int enc_chunk) : model(m) {
 Engine::~Engine() {
     (void)hipSetDevice(model->device);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    clear_graphs();
     for (int l = 0; l < kEncLanes; l++) {
         if (enc_streams_[l]) (void)hipStreamSynchronize(enc_streams_[l]);
         for (DevBuf *b : {&ews_[l].melT, &ews_[l].h1, &ews_[l].x, &ews_[l].xn, &ews_[l].q, &ews_[l].k, &ews_[l].vt, &ews_[l].att, &ews_[l].hid, &ews_[l].enc16}) b->release();
@@ -174,6 +176,12 @@ bool Engine::ensure_rows(int rows) {
 }
 
 // ------------------------------------------------------------------------------------------ profiling
+void Engine::clear_graphs() {
+    for (auto &kv : graphs_)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    graphs_.clear();
+}
+
 void Engine::prof_begin(int cls, double work) {
     if (!profiling || !((profile_mask >> cls) & 1u)) return;
     if (ev_used_ == ev_pool_.size()) {
@@ -254,10 +262,18 @@ int Engine::pcm_to_mel(const float *pcm, int n) {
     return 0;
 }
 
-int Engine::mel_batch_device(const float *pcm_dev, const long long *offs, const int *n, int B) {
+int Engine::mel_batch_device(const float *pcm_dev, const long long *offs, const int *n, int B, float *out_dev, int n_frames_out) {
     (void)hipSetDevice(model->device);
+    if (out_dev && (n_frames_out <= 0 || n_frames_out % 4 != 0)) return -1;
     std::vector<long> o(offs, offs + B); std::vector<int> nn(n, n + B);
     if (!compute_mel(pcm_dev, o, nn)) return -1;
+    if (out_dev) {      // the clamped, scaled log-mel -- what whisper_pcm_to_mel leaves -- for every utterance, into the caller's buffer
+        prof_stream_ = stream_;
+        prof_begin(WMI_K_MEL, 0.0);         // its bytes are counted with mel_raw_kernel's: PCM in, one log-mel out
+        const bool ok = mel_normalize_batch(mel_raw_.as<float>(), mel_utt_dev_.as<MelUtt>(), B, n_mel_, mel_max_.as<unsigned>(), out_dev, n_frames_out, stream_);
+        prof_end();
+        if (!ok) return -1;
+    }
     return hipStreamSynchronize(stream_) == hipSuccess ? 0 : -1;
 }
 
@@ -444,166 +460,207 @@ bool Engine::decoder_pass(std::vector<DecRow> &rows, const std::vector<SampleRow
     for (int r = 0; r < R; r++) if (rows[r].logit_row >= 0) gather[rows[r].logit_row] = r;
     if (C) memcpy(hb + o_copy, page_copies.data(), sizeof(int2) * C);
     if (max_group > 1) memcpy(hb + o_grp, xgroups_.data(), sizeof(int2) * NG);
-    WMI_HIP_OK(hipMemcpyAsync(meta_dev_.p, hb, total, hipMemcpyHostToDevice, stream_));
-    char *db = meta_dev_.as<char>();
-    const DecRow *d_rows = (const DecRow *)(db + o_rows);
-    const SampleRow *d_srow = (const SampleRow *)(db + o_srow);
-    const int *d_bt = (const int *)(db + o_bt), *d_gather = (const int *)(db + o_gather);
-    const int2 *d_copy = (const int2 *)(db + o_copy);
-    const int2 *d_grp = max_group > 1 ? (const int2 *)(db + o_grp) : nullptr;
-    f16 *kp = kpool_.as<f16>(), *vp = vpool_.as<f16>();
-    if (C) PROF(WMI_K_DEC_OTHER, 0, copy_pages(kp, vp, layer_stride_, Ld_, d_copy, C, H_, stream_));
-    const double w1 = 2.0 * d * d;           // bytes of one d x d fp16 weight
-    prof_stream_ = stream_;
-    // The decoder layers over rows [r0, r0 + Rn) of the pass (cross-attention row groups [g0, g0 + NGn)) on stream `st`, partial sums
-    // in `ws`. Three GEMM paths by row count, all with the same bits: at most 16 rows -- one launch per projection (LayerNorm in its
-    // prologue, bias / residual / GELU in its epilogue), 8 launches per layer; up to split_max_rows() -- split-K with consumers that
-    // also apply the epilogue and, for the residual GEMMs, the LayerNorm that follows; more -- fused-epilogue tiles + LayerNorm.
-    // Leaves the residual stream of its rows in dx_; the final LayerNorm of the logit rows follows on the pass's stream.
-    auto run_layers = [&](int r0, int Rn, int g0, int NGn, int max_grp, hipStream_t st, float *ws, size_t ws_cap) -> bool {
-        float *x = dx_.as<float>() + (size_t)r0 * d;
-        f16 *xn = dxn_.as<f16>() + (size_t)r0 * d, *q = dq_.as<f16>() + (size_t)r0 * d, *att = datt_.as<f16>() + (size_t)r0 * d, *hid = dhid_.as<f16>() + (size_t)r0 * 4 * d;
-        const DecRow *rw = d_rows + r0;
-        const double ln_bytes = (double)Rn * d * 6;
-        PROF(WMI_K_DEC_OTHER, (double)Rn * d * 6, dec_embed(model->d_te, model->d_pe, rw, Rn, d, x, st));
-        const bool may_split = (size_t)Rn <= split_max_rows();
-        const int s_qkv = may_split ? gemm_pick_splits(3 * d, d) : 1, s_dd = may_split ? gemm_pick_splits(d, d) : 1,
-                  s_fc1 = may_split ? gemm_pick_splits(4 * d, d) : 1, s_fc2 = may_split ? gemm_pick_splits(d, 4 * d) : 1;
-        const bool fused_ln = s_dd > 1 && s_fc2 > 1;      // x += ... and the next LayerNorm in one kernel
-        auto residual_ln = [&](const f16 *a, int K, const f16 *Wt, const float *bias, int splits, const float *lw, const float *lb) -> bool {
-            PROF(WMI_K_DEC_GEMM, 2.0 * d * K, gemm_splitk(a, K, Wt, K, Rn, d, K, splits, ws, ws_cap, st));
-            PROF(WMI_K_DEC_OTHER, ln_bytes, splitk_residual_ln(x, ws, splits, bias, lw, lb, xn, Rn, d, nullptr, Rn, st));
-            return true;
-        };
-        auto cross = [&](int l) -> bool {
-            if (mq && max_grp > 1)      // the group lists hold pass-wide row numbers: buffers from row 0
-                PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp + g0, NGn, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), st));
-            else if (max_grp > 1)
-                PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp + g0, NGn, max_grp, Rn, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), st));
-            else
-                PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention(q, ckv_.as<f16>(), rw, nullptr, NGn, 1, Rn, d, H_, T, Tp_full_, Ld_, l, att, st));
-            return true;
-        };
-        const bool few_rows = few_rows_path() && gemm_rows_ok(Rn, d, d, true) && gemm_rows_ok(Rn, d, 4 * d, false);
-        if (fused_ln && !few_rows) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, model->dec[0].ln1_w, model->dec[0].ln1_b, xn, nullptr, Rn, d, nullptr, st));
-        for (int l = 0; l < Ld_; l++) {
-            const DecLayer &D = model->dec[l];
-            f16 *kl = kp + l * layer_stride_, *vl = vp + l * layer_stride_;
-            if (few_rows) {
-                auto qw = [&](const QuantW &qq) -> const QuantW * { return quant_decode && qq.ttype ? &qq : nullptr; };
-                PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_rows_ln_dec_qkv(x, D.ln1_w, D.ln1_b, D.wqkv, Rn, d, H_, q, kl, vl, D.bqkv, rw, st, qw(D.q_wqkv)));
+    bool any_probs = false;
+    for (const SampleRow &s : srows) any_probs |= s.want_probs != 0;
+    if (L > 0 && any_probs && (!probs_.ensure((size_t)lrows_cap_ * V_ * sizeof(float), false) || !probs_host_.ensure((size_t)lrows_cap_ * V_ * sizeof(float)))) return false;
+    bool any_extra = any_probs;
+    for (const SampleRow &s : srows) any_extra |= s.topk > 0;
+    // Everything the pass puts on its stream, from the metadata upload to the download of the selections. What varies from one
+    // pass to the next of the same shape -- tokens, positions, page tables, sampling state -- travels in the metadata buffer, so
+    // the sequence of commands and their arguments is a function of the shape alone: see the graph replay below.
+    auto enqueue = [&]() -> bool {
+        WMI_HIP_OK(hipMemcpyAsync(meta_dev_.p, hb, total, hipMemcpyHostToDevice, stream_));
+        char *db = meta_dev_.as<char>();
+        const DecRow *d_rows = (const DecRow *)(db + o_rows);
+        const SampleRow *d_srow = (const SampleRow *)(db + o_srow);
+        const int *d_bt = (const int *)(db + o_bt), *d_gather = (const int *)(db + o_gather);
+        const int2 *d_copy = (const int2 *)(db + o_copy);
+        const int2 *d_grp = max_group > 1 ? (const int2 *)(db + o_grp) : nullptr;
+        f16 *kp = kpool_.as<f16>(), *vp = vpool_.as<f16>();
+        if (C) PROF(WMI_K_DEC_OTHER, 0, copy_pages(kp, vp, layer_stride_, Ld_, d_copy, C, H_, stream_));
+        const double w1 = 2.0 * d * d;           // bytes of one d x d fp16 weight
+        prof_stream_ = stream_;
+        // The decoder layers over rows [r0, r0 + Rn) of the pass (cross-attention row groups [g0, g0 + NGn)) on stream `st`, partial sums
+        // in `ws`. Three GEMM paths by row count, all with the same bits: at most 16 rows -- one launch per projection (LayerNorm in its
+        // prologue, bias / residual / GELU in its epilogue), 8 launches per layer; up to split_max_rows() -- split-K with consumers that
+        // also apply the epilogue and, for the residual GEMMs, the LayerNorm that follows; more -- fused-epilogue tiles + LayerNorm.
+        // Leaves the residual stream of its rows in dx_; the final LayerNorm of the logit rows follows on the pass's stream.
+        auto run_layers = [&](int r0, int Rn, int g0, int NGn, int max_grp, hipStream_t st, float *ws, size_t ws_cap) -> bool {
+            float *x = dx_.as<float>() + (size_t)r0 * d;
+            f16 *xn = dxn_.as<f16>() + (size_t)r0 * d, *q = dq_.as<f16>() + (size_t)r0 * d, *att = datt_.as<f16>() + (size_t)r0 * d, *hid = dhid_.as<f16>() + (size_t)r0 * 4 * d;
+            const DecRow *rw = d_rows + r0;
+            const double ln_bytes = (double)Rn * d * 6;
+            PROF(WMI_K_DEC_OTHER, (double)Rn * d * 6, dec_embed(model->d_te, model->d_pe, rw, Rn, d, x, st));
+            const bool may_split = (size_t)Rn <= split_max_rows();
+            const int s_qkv = may_split ? gemm_pick_splits(3 * d, d) : 1, s_dd = may_split ? gemm_pick_splits(d, d) : 1,
+                      s_fc1 = may_split ? gemm_pick_splits(4 * d, d) : 1, s_fc2 = may_split ? gemm_pick_splits(d, 4 * d) : 1;
+            const bool fused_ln = s_dd > 1 && s_fc2 > 1;      // x += ... and the next LayerNorm in one kernel
+            auto residual_ln = [&](const f16 *a, int K, const f16 *Wt, const float *bias, int splits, const float *lw, const float *lb) -> bool {
+                PROF(WMI_K_DEC_GEMM, 2.0 * d * K, gemm_splitk(a, K, Wt, K, Rn, d, K, splits, ws, ws_cap, st));
+                PROF(WMI_K_DEC_OTHER, ln_bytes, splitk_residual_ln(x, ws, splits, bias, lw, lb, xn, Rn, d, nullptr, Rn, st));
+                return true;
+            };
+            auto cross = [&](int l) -> bool {
+                if (mq && max_grp > 1)      // the group lists hold pass-wide row numbers: buffers from row 0
+                    PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention_mq(dq_.as<f16>(), ckv_.as<f16>(), ckvt_.as<f16>(), d_rows, d_grp + g0, NGn, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), st));
+                else if (max_grp > 1)
+                    PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention(dq_.as<f16>(), ckv_.as<f16>(), d_rows, d_grp + g0, NGn, max_grp, Rn, d, H_, T, Tp_full_, Ld_, l, datt_.as<f16>(), st));
+                else
+                    PROF(WMI_K_DEC_CROSS_ATTN, (double)NGn * 2.0 * T * d * 2, dec_cross_attention(q, ckv_.as<f16>(), rw, nullptr, NGn, 1, Rn, d, H_, T, Tp_full_, Ld_, l, att, st));
+                return true;
+            };
+            const bool few_rows = few_rows_path() && gemm_rows_ok(Rn, d, d, true) && gemm_rows_ok(Rn, d, 4 * d, false);
+            if (fused_ln && !few_rows) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, model->dec[0].ln1_w, model->dec[0].ln1_b, xn, nullptr, Rn, d, nullptr, st));
+            for (int l = 0; l < Ld_; l++) {
+                const DecLayer &D = model->dec[l];
+                f16 *kl = kp + l * layer_stride_, *vl = vp + l * layer_stride_;
+                if (few_rows) {
+                    auto qw = [&](const QuantW &qq) -> const QuantW * { return quant_decode && qq.ttype ? &qq : nullptr; };
+                    PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_rows_ln_dec_qkv(x, D.ln1_w, D.ln1_b, D.wqkv, Rn, d, H_, q, kl, vl, D.bqkv, rw, st, qw(D.q_wqkv)));
+                    PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(q, kl, vl, d_bt, rw, Rn, d, H_, att, st));
+                    PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(att, d, D.wo, Rn, d, d, x, d, D.bo, st, qw(D.q_wo)));
+                    PROF(WMI_K_DEC_GEMM, w1, gemm_rows_ln_f16(x, D.lnx_w, D.lnx_b, D.xq, Rn, d, d, q, d, D.bxq, 0, 0.125f, st, qw(D.q_xq)));
+                    if (!cross(l)) return false;
+                    PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(att, d, D.xo, Rn, d, d, x, d, D.bxo, st, qw(D.q_xo)));
+                    PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_ln_f16(x, D.ln2_w, D.ln2_b, D.fc1, Rn, 4 * d, d, hid, 4 * d, D.b1, 1, 1.0f, st, qw(D.q_fc1)));
+                    PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_residual(hid, 4 * d, D.fc2, Rn, d, 4 * d, x, d, D.b2, st, qw(D.q_fc2)));
+                    continue;
+                }
+                if (!fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.ln1_w, D.ln1_b, xn, nullptr, Rn, d, nullptr, st));
+                if (s_qkv > 1) {
+                    PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_splitk(xn, d, D.wqkv, d, Rn, 3 * d, d, s_qkv, ws, ws_cap, st));
+                    PROF(WMI_K_DEC_OTHER, (double)Rn * 3 * d * 2, splitk_dec_qkv(ws, s_qkv, D.bqkv, rw, Rn, d, H_, q, kl, vl, st));
+                } else {
+                    PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_dec_qkv(xn, D.wqkv, Rn, d, H_, q, kl, vl, D.bqkv, rw, st));
+                }
                 PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(q, kl, vl, d_bt, rw, Rn, d, H_, att, st));
-                PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(att, d, D.wo, Rn, d, d, x, d, D.bo, st, qw(D.q_wo)));
-                PROF(WMI_K_DEC_GEMM, w1, gemm_rows_ln_f16(x, D.lnx_w, D.lnx_b, D.xq, Rn, d, d, q, d, D.bxq, 0, 0.125f, st, qw(D.q_xq)));
+                if (fused_ln) { if (!residual_ln(att, d, D.wo, D.bo, s_dd, D.lnx_w, D.lnx_b)) return false; }
+                else {
+                    PROF(WMI_K_DEC_GEMM, w1, gemm_residual(att, d, D.wo, d, Rn, d, d, x, d, D.bo, st, true));
+                    PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.lnx_w, D.lnx_b, xn, nullptr, Rn, d, nullptr, st));
+                }
+                if (s_dd > 1) {
+                    PROF(WMI_K_DEC_GEMM, w1, gemm_splitk(xn, d, D.xq, d, Rn, d, d, s_dd, ws, ws_cap, st));
+                    PROF(WMI_K_DEC_OTHER, (double)Rn * d * 2, splitk_f16(ws, s_dd, D.bxq, 0, 0.125f, q, Rn, d, st));
+                } else {
+                    PROF(WMI_K_DEC_GEMM, w1, gemm_f16(xn, d, D.xq, d, Rn, d, d, q, d, D.bxq, 0, 0.125f, st, true));
+                }
                 if (!cross(l)) return false;
-                PROF(WMI_K_DEC_GEMM, w1, gemm_rows_residual(att, d, D.xo, Rn, d, d, x, d, D.bxo, st, qw(D.q_xo)));
-                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_ln_f16(x, D.ln2_w, D.ln2_b, D.fc1, Rn, 4 * d, d, hid, 4 * d, D.b1, 1, 1.0f, st, qw(D.q_fc1)));
-                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_rows_residual(hid, 4 * d, D.fc2, Rn, d, 4 * d, x, d, D.b2, st, qw(D.q_fc2)));
-                continue;
+                if (fused_ln) { if (!residual_ln(att, d, D.xo, D.bxo, s_dd, D.ln2_w, D.ln2_b)) return false; }
+                else {
+                    PROF(WMI_K_DEC_GEMM, w1, gemm_residual(att, d, D.xo, d, Rn, d, d, x, d, D.bxo, st, true));
+                    PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.ln2_w, D.ln2_b, xn, nullptr, Rn, d, nullptr, st));
+                }
+                if (s_fc1 > 1) {
+                    PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_splitk(xn, d, D.fc1, d, Rn, 4 * d, d, s_fc1, ws, ws_cap, st));
+                    PROF(WMI_K_DEC_OTHER, (double)Rn * 4 * d * 2, splitk_f16(ws, s_fc1, D.b1, 1, 1.0f, hid, Rn, 4 * d, st));
+                } else {
+                    PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(xn, d, D.fc1, d, Rn, 4 * d, d, hid, 4 * d, D.b1, 1, 1.0f, st, true));
+                }
+                if (fused_ln) {
+                    // (after the last layer the LayerNorm this writes is not used: the logit rows get theirs below)
+                    const float *lw = l + 1 < Ld_ ? model->dec[l + 1].ln1_w : model->d_ln_w, *lb = l + 1 < Ld_ ? model->dec[l + 1].ln1_b : model->d_ln_b;
+                    if (!residual_ln(hid, 4 * d, D.fc2, D.b2, s_fc2, lw, lb)) return false;
+                } else {
+                    PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_residual(hid, 4 * d, D.fc2, 4 * d, Rn, d, 4 * d, x, d, D.b2, st, true));
+                }
             }
-            if (!fused_ln) PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.ln1_w, D.ln1_b, xn, nullptr, Rn, d, nullptr, st));
-            if (s_qkv > 1) {
-                PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_splitk(xn, d, D.wqkv, d, Rn, 3 * d, d, s_qkv, ws, ws_cap, st));
-                PROF(WMI_K_DEC_OTHER, (double)Rn * 3 * d * 2, splitk_dec_qkv(ws, s_qkv, D.bqkv, rw, Rn, d, H_, q, kl, vl, st));
-            } else {
-                PROF(WMI_K_DEC_GEMM, 3 * w1, gemm_dec_qkv(xn, D.wqkv, Rn, d, H_, q, kl, vl, D.bqkv, rw, st));
+            return true;
+        };
+        // Row lanes: the kernels of a pass of a few hundred rows are chains of dependent 5-30 us launches that leave most of the chip
+        // idle (100-400 workgroups, each bound by its own latency chain). Two halves of the rows on two streams run two such chains
+        // side by side; since no path's arithmetic depends on the rows that share its launches, the halves give the bits the whole
+        // pass would. The pass's stream forks after the metadata upload and joins before the logits.
+        const bool prof_dec = profiling && (profile_mask & ((1u << WMI_K_DEC_GEMM) | (1u << WMI_K_DEC_OTHER) | (1u << WMI_K_DEC_CROSS_ATTN)));
+        int cut_row = 0, cut_grp = 0;
+        if (dec_lanes_ > 1 && !prof_dec && R >= 2 * kDecLaneMinRows && lane_stream_ && lane_ws_.p) {
+            // cut at the cross-attention group boundary nearest to the middle (rows of one utterance stay in one lane)
+            int best = -1;
+            for (int gi = 1; gi < NG; gi++) {
+                const int r = xgroups_[gi].x;
+                if (xgroups_[gi - 1].x + xgroups_[gi - 1].y == r && rows[r].utt != rows[r - 1].utt && (best < 0 || abs(r - R / 2) < abs(xgroups_[best].x - R / 2))) best = gi;
             }
-            PROF(WMI_K_DEC_OTHER, 0, dec_self_attention(q, kl, vl, d_bt, rw, Rn, d, H_, att, st));
-            if (fused_ln) { if (!residual_ln(att, d, D.wo, D.bo, s_dd, D.lnx_w, D.lnx_b)) return false; }
-            else {
-                PROF(WMI_K_DEC_GEMM, w1, gemm_residual(att, d, D.wo, d, Rn, d, d, x, d, D.bo, st, true));
-                PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.lnx_w, D.lnx_b, xn, nullptr, Rn, d, nullptr, st));
+            if (best > 0 && xgroups_[best].x >= kDecLaneMinRows && R - xgroups_[best].x >= kDecLaneMinRows) { cut_grp = best; cut_row = xgroups_[best].x; }
+        }
+        if (cut_row > 0) {
+            int mg0 = 1, mg1 = 1;
+            for (int gi = 0; gi < NG; gi++) (gi < cut_grp ? mg0 : mg1) = std::max(gi < cut_grp ? mg0 : mg1, xgroups_[gi].y);
+            WMI_HIP_OK(hipEventRecord(lane_fork_, stream_));
+            WMI_HIP_OK(hipStreamWaitEvent(lane_stream_, lane_fork_, 0));
+            const bool ok1 = run_layers(cut_row, R - cut_row, cut_grp, NG - cut_grp, mg1, lane_stream_, lane_ws_.as<float>(), lane_ws_.cap);
+            const bool ok0 = run_layers(0, cut_row, 0, cut_grp, mg0, stream_, splitk_ws_.as<float>(), splitk_ws_.cap);
+            // join even when a launch failed: nothing may still run on the lane when this pass returns
+            WMI_HIP_OK(hipEventRecord(lane_join_, lane_stream_));
+            WMI_HIP_OK(hipStreamWaitEvent(stream_, lane_join_, 0));
+            if (!ok0 || !ok1) { (void)hipStreamSynchronize(stream_); return false; }
+        } else {
+            if (!run_layers(0, R, 0, NG, max_group, stream_, splitk_ws_.as<float>(), splitk_ws_.cap)) return false;
+        }
+        if (L > 0) {
+            PROF(WMI_K_DEC_OTHER, (double)L * d * 6, layer_norm(dx_.as<float>(), model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), nullptr, L, d, d_gather, stream_));
+            PROF(WMI_K_DEC_GEMM, 2.0 * Vp_ * d + 4.0 * L * Vp_, gemm_f32(dxl_.as<f16>(), d, model->d_te, d, L, Vp_, d, logits_.as<float>(), Vp_, nullptr, stream_));
+            if (logits_all_out) WMI_HIP_OK(hipMemcpy2DAsync(logits_all_out, sizeof(float) * V_, logits_.p, sizeof(float) * Vp_, sizeof(float) * V_, L, hipMemcpyDeviceToHost, stream_));
+            if (want_raw_logits_host) WMI_HIP_OK(hipMemcpyAsync(logits_host_.data(), logits_.as<float>() + (size_t)(L - 1) * Vp_, sizeof(float) * V_, hipMemcpyDeviceToHost, stream_));
+            SampleOut *d_out = out_dev_.as<SampleOut>();
+            TopkOut *d_topk = (TopkOut *)(out_dev_.as<char>() + sizeof(SampleOut) * lrows_cap_);
+            if (filter) {
+                // whisper_full hands the logits to the caller's filter after the temperature and the special-token suppression and
+                // applies the remaining rules to what the filter leaves: first half of the rules, rows to the host and back, second half
+                std::vector<SampleRow> half(srows);
+                for (SampleRow &r : half) r.flags |= 512;
+                filter_rows_.resize((size_t)L * V_);
+                WMI_HIP_OK(hipMemcpyAsync(meta_dev_.as<char>() + o_srow, half.data(), sizeof(SampleRow) * L, hipMemcpyHostToDevice, stream_));
+                if (!sample_rows(logits_.as<float>(), Vp_, L, d_srow, model->vocab_ids(), model->nst_bitmap, d_out, d_topk, 8, nullptr, false, sample_ws_.p, stream_)) return false;
+                WMI_HIP_OK(hipMemcpy2DAsync(filter_rows_.data(), sizeof(float) * V_, logits_.p, sizeof(float) * Vp_, sizeof(float) * V_, L, hipMemcpyDeviceToHost, stream_));
+                WMI_HIP_OK(hipStreamSynchronize(stream_));
+                for (int r = 0; r < L; r++) (*filter)(r, filter_rows_.data() + (size_t)r * V_);
+                for (SampleRow &r : half) r.flags = (r.flags & ~512) | 1024;
+                WMI_HIP_OK(hipMemcpy2DAsync(logits_.p, sizeof(float) * Vp_, filter_rows_.data(), sizeof(float) * V_, sizeof(float) * V_, L, hipMemcpyHostToDevice, stream_));
+                WMI_HIP_OK(hipMemcpyAsync(meta_dev_.as<char>() + o_srow, half.data(), sizeof(SampleRow) * L, hipMemcpyHostToDevice, stream_));
+                WMI_HIP_OK(hipStreamSynchronize(stream_));        // `half` leaves scope below; the copies above read pageable host memory
             }
-            if (s_dd > 1) {
-                PROF(WMI_K_DEC_GEMM, w1, gemm_splitk(xn, d, D.xq, d, Rn, d, d, s_dd, ws, ws_cap, st));
-                PROF(WMI_K_DEC_OTHER, (double)Rn * d * 2, splitk_f16(ws, s_dd, D.bxq, 0, 0.125f, q, Rn, d, st));
-            } else {
-                PROF(WMI_K_DEC_GEMM, w1, gemm_f16(xn, d, D.xq, d, Rn, d, d, q, d, D.bxq, 0, 0.125f, st, true));
-            }
-            if (!cross(l)) return false;
-            if (fused_ln) { if (!residual_ln(att, d, D.xo, D.bxo, s_dd, D.ln2_w, D.ln2_b)) return false; }
-            else {
-                PROF(WMI_K_DEC_GEMM, w1, gemm_residual(att, d, D.xo, d, Rn, d, d, x, d, D.bxo, st, true));
-                PROF(WMI_K_DEC_OTHER, ln_bytes, layer_norm(x, D.ln2_w, D.ln2_b, xn, nullptr, Rn, d, nullptr, st));
-            }
-            if (s_fc1 > 1) {
-                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_splitk(xn, d, D.fc1, d, Rn, 4 * d, d, s_fc1, ws, ws_cap, st));
-                PROF(WMI_K_DEC_OTHER, (double)Rn * 4 * d * 2, splitk_f16(ws, s_fc1, D.b1, 1, 1.0f, hid, Rn, 4 * d, st));
-            } else {
-                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_f16(xn, d, D.fc1, d, Rn, 4 * d, d, hid, 4 * d, D.b1, 1, 1.0f, st, true));
-            }
-            if (fused_ln) {
-                // (after the last layer the LayerNorm this writes is not used: the logit rows get theirs below)
-                const float *lw = l + 1 < Ld_ ? model->dec[l + 1].ln1_w : model->d_ln_w, *lb = l + 1 < Ld_ ? model->dec[l + 1].ln1_b : model->d_ln_b;
-                if (!residual_ln(hid, 4 * d, D.fc2, D.b2, s_fc2, lw, lb)) return false;
-            } else {
-                PROF(WMI_K_DEC_GEMM, 4 * w1, gemm_residual(hid, 4 * d, D.fc2, 4 * d, Rn, d, 4 * d, x, d, D.b2, st, true));
-            }
+            PROF(WMI_K_DEC_OTHER, 8.0 * L * V_, sample_rows(logits_.as<float>(), Vp_, L, d_srow, model->vocab_ids(), model->nst_bitmap, d_out, d_topk, 8,
+                                                           any_probs ? probs_.as<float>() : nullptr, any_extra, sample_ws_.p, stream_));
+            WMI_HIP_OK(hipMemcpyAsync(out_host_.p, out_dev_.p, sizeof(SampleOut) * lrows_cap_ + sizeof(TopkOut) * 8 * (size_t)L, hipMemcpyDeviceToHost, stream_));
+            if (any_probs) WMI_HIP_OK(hipMemcpyAsync(probs_host_.p, probs_.p, sizeof(float) * (size_t)L * V_, hipMemcpyDeviceToHost, stream_));
         }
         return true;
     };
-    // Row lanes: the kernels of a pass of a few hundred rows are chains of dependent 5-30 us launches that leave most of the chip
-    // idle (100-400 workgroups, each bound by its own latency chain). Two halves of the rows on two streams run two such chains
-    // side by side; since no path's arithmetic depends on the rows that share its launches, the halves give the bits the whole
-    // pass would. The pass's stream forks after the metadata upload and joins before the logits.
-    const bool prof_dec = profiling && (profile_mask & ((1u << WMI_K_DEC_GEMM) | (1u << WMI_K_DEC_OTHER) | (1u << WMI_K_DEC_CROSS_ATTN)));
-    int cut_row = 0, cut_grp = 0;
-    if (dec_lanes_ > 1 && !prof_dec && R >= 2 * kDecLaneMinRows && lane_stream_ && lane_ws_.p) {
-        // cut at the cross-attention group boundary nearest to the middle (rows of one utterance stay in one lane)
-        int best = -1;
-        for (int gi = 1; gi < NG; gi++) {
-            const int r = xgroups_[gi].x;
-            if (xgroups_[gi - 1].x + xgroups_[gi - 1].y == r && rows[r].utt != rows[r - 1].utt && (best < 0 || abs(r - R / 2) < abs(xgroups_[best].x - R / 2))) best = gi;
+    // Replay: a pass whose shape has been seen before runs as one HIP graph launch instead of the ~10 launches per layer it is
+    // made of (a one-clip step pass of large-v3-turbo: 42 kernels and two copies). The graph is captured from the very code above
+    // the second time a shape comes by -- the first time warms every kernel up, since nothing may be loaded or configured under
+    // capture -- and is keyed by everything the commands' arguments depend on, the buffers' addresses included.
+    bool launched = false;
+    const bool prof_any = profiling && profile_mask != 0;
+    if (use_graphs_ && !prof_any && !filter && !logits_all_out && !want_raw_logits_host && !any_probs && dec_lanes_ <= 1) {
+        uintptr_t ptrs = 0;
+        for (const void *q : {dx_.p, dxn_.p, dq_.p, datt_.p, dhid_.p, dxl_.p, logits_.p, meta_dev_.p, (void *)meta_host_.p, out_dev_.p, (void *)out_host_.p, ckv_.p, ckvt_.p,
+                              kpool_.p, vpool_.p, splitk_ws_.p, sample_ws_.p})
+            ptrs = ptrs * 1000003u ^ (uintptr_t)q;
+        const PassKey key{{R, L, S, C, NG, max_group, T, (int)any_extra | (mq ? 2 : 0) | (quant_decode ? 4 : 0), (int)(ptrs & 0x7fffffff), (int)((ptrs >> 31) & 0x7fffffff)}};
+        if (graphs_.size() > 64) clear_graphs();
+        PassGraph &g = graphs_[key];
+        if (g.exec) {
+            launched = hipGraphLaunch(g.exec, stream_) == hipSuccess;
+            if (!launched) { (void)hipGetLastError(); (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; g.bad = true; }
+        } else if (!g.bad && ++g.seen >= 2) {
+            if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const bool enq = enqueue();
+                hipGraph_t graph = nullptr;
+                const hipError_t e = hipStreamEndCapture(stream_, &graph);
+                if (enq && e == hipSuccess && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess && g.exec)
+                    launched = hipGraphLaunch(g.exec, stream_) == hipSuccess;
+                if (graph) (void)hipGraphDestroy(graph);
+                if (!launched) {
+                    (void)hipGetLastError();
+                    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+                    g.bad = true;
+                    log_msg(1, "engine: a decoder pass of %d rows could not be captured as a graph; it keeps running as plain launches\n", R);
+                }
+            } else { (void)hipGetLastError(); g.bad = true; }
         }
-        if (best > 0 && xgroups_[best].x >= kDecLaneMinRows && R - xgroups_[best].x >= kDecLaneMinRows) { cut_grp = best; cut_row = xgroups_[best].x; }
     }
-    if (cut_row > 0) {
-        int mg0 = 1, mg1 = 1;
-        for (int gi = 0; gi < NG; gi++) (gi < cut_grp ? mg0 : mg1) = std::max(gi < cut_grp ? mg0 : mg1, xgroups_[gi].y);
-        WMI_HIP_OK(hipEventRecord(lane_fork_, stream_));
-        WMI_HIP_OK(hipStreamWaitEvent(lane_stream_, lane_fork_, 0));
-        const bool ok1 = run_layers(cut_row, R - cut_row, cut_grp, NG - cut_grp, mg1, lane_stream_, lane_ws_.as<float>(), lane_ws_.cap);
-        const bool ok0 = run_layers(0, cut_row, 0, cut_grp, mg0, stream_, splitk_ws_.as<float>(), splitk_ws_.cap);
-        // join even when a launch failed: nothing may still run on the lane when this pass returns
-        WMI_HIP_OK(hipEventRecord(lane_join_, lane_stream_));
-        WMI_HIP_OK(hipStreamWaitEvent(stream_, lane_join_, 0));
-        if (!ok0 || !ok1) { (void)hipStreamSynchronize(stream_); return false; }
-    } else {
-        if (!run_layers(0, R, 0, NG, max_group, stream_, splitk_ws_.as<float>(), splitk_ws_.cap)) return false;
-    }
-    if (L > 0) {
-        PROF(WMI_K_DEC_OTHER, (double)L * d * 6, layer_norm(dx_.as<float>(), model->d_ln_w, model->d_ln_b, dxl_.as<f16>(), nullptr, L, d, d_gather, stream_));
-        PROF(WMI_K_DEC_GEMM, 2.0 * Vp_ * d + 4.0 * L * Vp_, gemm_f32(dxl_.as<f16>(), d, model->d_te, d, L, Vp_, d, logits_.as<float>(), Vp_, nullptr, stream_));
-        if (logits_all_out) WMI_HIP_OK(hipMemcpy2DAsync(logits_all_out, sizeof(float) * V_, logits_.p, sizeof(float) * Vp_, sizeof(float) * V_, L, hipMemcpyDeviceToHost, stream_));
-        if (want_raw_logits_host) WMI_HIP_OK(hipMemcpyAsync(logits_host_.data(), logits_.as<float>() + (size_t)(L - 1) * Vp_, sizeof(float) * V_, hipMemcpyDeviceToHost, stream_));
-        bool any_probs = false;
-        for (const SampleRow &s : srows) any_probs |= s.want_probs != 0;
-        if (any_probs && (!probs_.ensure((size_t)lrows_cap_ * V_ * sizeof(float), false) || !probs_host_.ensure((size_t)lrows_cap_ * V_ * sizeof(float)))) return false;
-        SampleOut *d_out = out_dev_.as<SampleOut>();
-        TopkOut *d_topk = (TopkOut *)(out_dev_.as<char>() + sizeof(SampleOut) * lrows_cap_);
-        bool any_extra = any_probs;
-        for (const SampleRow &s : srows) any_extra |= s.topk > 0;
-        if (filter) {
-            // whisper_full hands the logits to the caller's filter after the temperature and the special-token suppression and
-            // applies the remaining rules to what the filter leaves: first half of the rules, rows to the host and back, second half
-            std::vector<SampleRow> half(srows);
-            for (SampleRow &r : half) r.flags |= 512;
-            filter_rows_.resize((size_t)L * V_);
-            WMI_HIP_OK(hipMemcpyAsync(meta_dev_.as<char>() + o_srow, half.data(), sizeof(SampleRow) * L, hipMemcpyHostToDevice, stream_));
-            if (!sample_rows(logits_.as<float>(), Vp_, L, d_srow, model->vocab_ids(), model->nst_bitmap, d_out, d_topk, 8, nullptr, false, sample_ws_.p, stream_)) return false;
-            WMI_HIP_OK(hipMemcpy2DAsync(filter_rows_.data(), sizeof(float) * V_, logits_.p, sizeof(float) * Vp_, sizeof(float) * V_, L, hipMemcpyDeviceToHost, stream_));
-            WMI_HIP_OK(hipStreamSynchronize(stream_));
-            for (int r = 0; r < L; r++) (*filter)(r, filter_rows_.data() + (size_t)r * V_);
-            for (SampleRow &r : half) r.flags = (r.flags & ~512) | 1024;
-            WMI_HIP_OK(hipMemcpy2DAsync(logits_.p, sizeof(float) * Vp_, filter_rows_.data(), sizeof(float) * V_, sizeof(float) * V_, L, hipMemcpyHostToDevice, stream_));
-            WMI_HIP_OK(hipMemcpyAsync(meta_dev_.as<char>() + o_srow, half.data(), sizeof(SampleRow) * L, hipMemcpyHostToDevice, stream_));
-            WMI_HIP_OK(hipStreamSynchronize(stream_));        // `half` leaves scope below; the copies above read pageable host memory
-        }
-        PROF(WMI_K_DEC_OTHER, 8.0 * L * V_, sample_rows(logits_.as<float>(), Vp_, L, d_srow, model->vocab_ids(), model->nst_bitmap, d_out, d_topk, 8,
-                                                       any_probs ? probs_.as<float>() : nullptr, any_extra, sample_ws_.p, stream_));
-        WMI_HIP_OK(hipMemcpyAsync(out_host_.p, out_dev_.p, sizeof(SampleOut) * lrows_cap_ + sizeof(TopkOut) * 8 * (size_t)L, hipMemcpyDeviceToHost, stream_));
-        if (any_probs) WMI_HIP_OK(hipMemcpyAsync(probs_host_.p, probs_.p, sizeof(float) * (size_t)L * V_, hipMemcpyDeviceToHost, stream_));
-    }
+    if (!launched && !enqueue()) return false;
     const double t_launched = now_ms();
     WMI_HIP_OK(hipStreamSynchronize(stream_));
     t_dec_launch_ms += t_launched - t_pass0; t_dec_wait_ms += now_ms() - t_launched; n_passes++;

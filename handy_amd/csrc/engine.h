@@ -1,7 +1,9 @@
 // Batched whisper_full engine: per-utterance state machines on the host drive batched encoder
 // chunks and decoder passes on one GPU stream.
 #pragma once
+#include <array>
 #include <functional>
+#include <map>
 #include <random>
 #include <string>
 #include <deque>
@@ -106,7 +108,7 @@ public:
 
     // low-level stages (utterance slot 0)
     int pcm_to_mel(const float *pcm, int n);
-    int mel_batch_device(const float *pcm_dev, const long long *offs, const int *n, int B);
+    int mel_batch_device(const float *pcm_dev, const long long *offs, const int *n, int B, float *out_dev = nullptr, int n_frames_out = 0);
     int set_mel(const float *data, int n_len, int n_mel);
     int encode(int offset, int audio_ctx);
     int decode(const int *tokens, int n_tokens, int n_past, bool logits_all, float *logits_all_out);
@@ -133,7 +135,8 @@ public:
     // profiling
     bool profiling = false;
     bool quant_decode = true;
-    void set_decoder_lanes(int n) { dec_lanes_ = n < 1 ? 1 : (n > 2 ? 2 : n); }           // few-row decode passes read the decoder weights as the file's blocks where the model holds them
+    void set_decoder_lanes(int n) { dec_lanes_ = n < 1 ? 1 : (n > 2 ? 2 : n); }
+    void set_pass_graphs(bool on) { use_graphs_ = on; if (!on) clear_graphs(); }    // decoder passes of a repeated shape replayed as HIP graphs (default on)           // few-row decode passes read the decoder weights as the file's blocks where the model holds them
     unsigned profile_mask = ~0u;        // bit per wmi_kernel_class: which classes get event pairs while profiling is on
     wmi_kernel_stat stats[WMI_K_COUNT]{};
     void collect_stats();
@@ -196,6 +199,13 @@ private:
     std::vector<float> filter_rows_;  // logit rows on the host while the caller's logits_filter_callback looks at them
     Decoder ll_dec_;                 // sequence used by whisper_decode()
     std::vector<int2> xgroups_;      // cross-attention row groups of the pass being built
+
+    // decoder passes replayed as HIP graphs, by pass shape (decoder_pass)
+    struct PassKey { std::array<int, 10> v; bool operator<(const PassKey &o) const { return v < o.v; } };
+    struct PassGraph { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; };
+    std::map<PassKey, PassGraph> graphs_;
+    bool use_graphs_ = true;
+    void clear_graphs();
 
     // event pool for profiling
     struct EvPair { hipEvent_t a, b; int cls; double work; };

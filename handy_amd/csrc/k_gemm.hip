@@ -269,6 +269,8 @@ template <class Epi> struct is_splitk<Epi, decltype((void)Epi::kSplitK)> { stati
 // Epilogues that map a row (or column) index to (utterance, frame) offer begin_tile(m0, n0): one integer division per
 // tile there instead of one per store (a 256-wide tile spans at most two utterances, so a compare finishes the job;
 // the compiler's division sequence is ~30 instructions, and the staged epilogue makes 16-32 stores per lane).
+template <class Epi, class = void> struct epi_modes { static constexpr int value = 1; };
+template <class Epi> struct epi_modes<Epi, decltype((void)Epi::kModes)> { static constexpr int value = Epi::kModes; };
 template <class Epi, class = void> struct has_begin_tile { static constexpr bool value = false; };
 template <class Epi> struct has_begin_tile<Epi, decltype((void)&Epi::begin_tile)> { static constexpr bool value = true; };
 // kStoresPerTile: global store instructions one wave issues in the staged epilogue of a tile whose every row (and, where the
@@ -1086,7 +1088,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const f16 *__restrict__ 
         else relaxed = m0 + 256 <= M;
         if constexpr (Epi::kWide) {
             if (epi.wide_block(n0, 256)) {
-                if constexpr (has_col_bias<Epi>::value && Epi::kModes == 4) {
+                if constexpr (has_col_bias<Epi>::value && epi_modes<Epi>::value == 4) {
                     switch (epi.mode()) {                          // wave-uniform: one straight-line body per mode
                         case 0: write_tile_halves<Epi, 0>(epi, acc, M, m0, n0, map, wave_e, lane_e, stg); break;
                         case 1: write_tile_halves<Epi, 1>(epi, acc, M, m0, n0, map, wave_e, lane_e, stg); break;
@@ -1193,7 +1195,8 @@ static bool launch(const f16 *A, long lda, const f16 *W, long ldw, int M, int N,
     return hipGetLastError() == hipSuccess;
 }
 
-// Tile choice: 256x256 (the 8-phase kernel; for K = 64 the 2-stage kernel with the LDS-DMA issue spread over the MFMA
+// Tile choice: 256x256 (the 8-phase kernel -- its persistent form, one workgroup per CU walking the tiles, when there are two
+// or more tiles per CU and K/64 is even; for K = 64 the 2-stage kernel with the LDS-DMA issue spread over the MFMA
 // groups) when N allows it and the grid fills the chip, then
 // 256x128 (8 waves, 3 stages, one workgroup per CU) when that grid still fills the chip,
 // 64x64 (4 waves, 4 stages) for the skinny decoder-side problems. Activation buffers are allocated with
@@ -1207,6 +1210,7 @@ static bool dispatch(const f16 *A, long lda, const f16 *W, long ldw, int M, int 
     // one clip's encoder (1500 rows) at N = 4d: 6 x 20 tiles of 256 x 256 leave half the CUs idle, 6 x 40 of 256 x 128 fill them
     // (large-v3-turbo fc1: 34.5 -> 27.0 us; same bits)
     if (M <= 1536 && N % 128 == 0 && N <= 8192 && big >= 192) return launch<256, 128, 4, 2, 3, Epi>(A, lda, W, ldw, M, N, K, epi, st);
+    if (persistent_ok(M, N, K)) return launch8p<Epi>(A, lda, W, ldw, M, N, K, epi, st);       // two or more tiles per CU: the persistent form
     if (N % 256 == 0 && big >= 192 && K >= 2 * BK) return launch8<Epi>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 256 == 0 && big >= 192) return launch<256, 256, 2, 4, 2, Epi, kSpread | kFirstHalf>(A, lda, W, ldw, M, N, K, epi, st);
     if (N % 128 == 0 && M >= 192 && big >= 128) return launch<256, 128, 4, 2, 3, Epi>(A, lda, W, ldw, M, N, K, epi, st);
@@ -1705,6 +1709,7 @@ bool gemm_enc_qk(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp
 bool gemm_enc_vt(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Vt, const float *bias, hipStream_t st) {
     if (!gemm_enc_qkv_is_split(M, d, T)) return false;
     const int Mp = (M + 255) / 256 * 256;
+    if (persistent_ok(d, Mp, d)) return launch8p<EpiVt>(W + (long)2 * d * d, d, xn, d, d, Mp, d, EpiVt{Vt, bias + 2 * d, H, T, Tp, M}, st, d / 256);
     return launch8<EpiVt>(W + (long)2 * d * d, d, xn, d, d, Mp, d, EpiVt{Vt, bias + 2 * d, H, T, Tp, M}, st, d / 256);
 }
 bool gemm_enc_qkv(const f16 *xn, const f16 *W, int M, int d, int H, int T, int Tp, f16 *Q, f16 *Kb, f16 *Vt, const float *bias, hipStream_t st) {

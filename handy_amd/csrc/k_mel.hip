@@ -20,6 +20,8 @@
 // Bound: HBM. Algorithmic bytes per 30 s utterance: 480000*4 in + n_mel*3000*4 out.
 #include "kernels.h"
 
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 
 namespace wmi {
@@ -286,6 +288,33 @@ bool mel_normalize(const float *raw, int n_mel, int n_frames, const unsigned *me
     return hipGetLastError() == hipSuccess;
 }
 
+// The clamp / scale pass for a whole batch: out[b][j][t], t < n_out, = the normalised log-mel of utterance b (frames past the
+// ones computed carry the floor value). It runs right behind mel_raw_kernel, whose output (184 MB for an hour of audio at
+// 128 mel bins) is still in the Infinity Cache; four frames per thread, 16-byte loads and stores.
+__global__ __launch_bounds__(256) void mel_normalize_batch_kernel(const float *__restrict__ raw, const MelUtt *__restrict__ utts, int n_mel,
+                                                                  const unsigned *__restrict__ mel_max, float *__restrict__ out, int n_out) {
+    const MelUtt u = utts[blockIdx.y];
+    const float mmax = fmaxf(from_ordered_bits(mel_max[blockIdx.y]), -10.0f);
+    const int q_per_row = n_out >> 2;                      // n_out % 4 == 0 (checked by the launcher)
+    const long total = (long)n_mel * q_per_row;
+    const float *src = raw + u.mel_off;
+    float *dst = out + (long)blockIdx.y * n_mel * n_out;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i / q_per_row), t = (int)(i - (long)j * q_per_row) * 4;
+        f32x4 v = {-10.0f, -10.0f, -10.0f, -10.0f};
+        if (t + 4 <= u.n_frames) v = *(const f32x4 *)(src + (long)j * u.n_frames + t);          // n_frames % 32 == 0: whole or nothing
+        *(f32x4 *)(dst + (long)j * n_out + t) = f32x4{mel_norm_value(v[0], mmax), mel_norm_value(v[1], mmax), mel_norm_value(v[2], mmax), mel_norm_value(v[3], mmax)};
+    }
+}
+bool mel_normalize_batch(const float *raw, const MelUtt *utts, int n_utt, int n_mel, const unsigned *mel_max, float *out, int n_out, hipStream_t st) {
+    if (n_utt <= 0) return true;
+    if (n_out <= 0 || n_out % 4 != 0) return false;
+    const long total = (long)n_mel * (n_out >> 2);
+    const int bx = (int)std::min<long>((total + 255) / 256, 96);
+    hipLaunchKernelGGL(mel_normalize_batch_kernel, dim3(bx, n_utt), dim3(256), 0, st, raw, utts, n_mel, mel_max, out, n_out);
+    return hipGetLastError() == hipSuccess;
+}
+
 // ------------------------------------------------------------------------------------------ log-mel without allocations
 // The frontend for callers that may not allocate (code under HIP graph capture, serving loops, harnesses that forbid
 // hipMalloc): one utterance of at most kMelNoAllocMaxSamples samples, PCM and result in the caller's device memory. What
@@ -301,18 +330,19 @@ constexpr size_t kMelScratchBytes = kMelScratchHeader + (size_t)128 * kMelNoAllo
 static __device__ __align__(256) unsigned char scratch[kMelScratchBytes];
 
 constexpr int kMaxDevices = 64;
-static unsigned char *g_scratch_ptr[kMaxDevices] = {};
+static std::atomic<unsigned char *> g_scratch_ptr[kMaxDevices];
 static std::mutex g_scratch_mu;
 
-// `device` must be the current device.
+// Set-up, at context creation: `device` must be the current device. The look-up may load the code object on that device
+// (an allocation), which is why it happens here and never inside the entry point.
 bool mel_noalloc_init(int device) {
     if (device < 0 || device >= kMaxDevices) return false;
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (g_scratch_ptr[device]) return true;
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return true;
     void *p = nullptr;
     const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !p) { log_msg(2, "mel_noalloc_init: hipGetSymbolAddress failed on device %d: %s\n", device, hipGetErrorString(e)); return false; }
-    g_scratch_ptr[device] = (unsigned char *)p;
+    g_scratch_ptr[device].store((unsigned char *)p, std::memory_order_release);
     return true;
 }
 
@@ -324,8 +354,9 @@ int mel_noalloc(const float *pcm_dev, int n, const MelTables &tb, float *out_dev
         log_msg(2, "wmi_pcm_to_mel_device_noalloc: %d samples / %d frames exceed the entry point's maximum of %d samples / %d frames\n", n, n_out, kMelNoAllocMaxSamples, kMelNoAllocMaxFramesOut);
         return -2;
     }
-    if (device < 0 || device >= kMaxDevices || (!g_scratch_ptr[device] && !mel_noalloc_init(device))) return -3;
-    unsigned char *ptr = g_scratch_ptr[device];
+    // the array's address on this device was looked up when the context was created; it is not looked up here (that can allocate)
+    unsigned char *ptr = device >= 0 && device < kMaxDevices ? g_scratch_ptr[device].load(std::memory_order_acquire) : nullptr;
+    if (!ptr) { log_msg(2, "wmi_pcm_to_mel_device_noalloc: no context has been created on device %d\n", device); return -3; }
     unsigned *mel_max = (unsigned *)ptr;
     float *raw = (float *)(ptr + kMelScratchHeader);
     MelUtt u{};

@@ -72,6 +72,8 @@ constexpr int kMelFramesPerBlock = 32;
 bool mel_raw(const float *pcm, const MelUtt *utts, int n_utt, int max_blocks_per_utt, const MelTables &tb, float *mel_raw, unsigned *mel_max, hipStream_t st);
 // normalised copy: out[j][i] for i < n_out frames (clamp to max-8, (x+4)/4); frames past n_frames read as -10
 bool mel_normalize(const float *raw, int n_mel, int n_frames, const unsigned *mel_max, float *out, int n_out, hipStream_t st);
+// the same for every utterance of a mel_raw call at once: out[b][n_mel][n_out] (n_out % 4 == 0)
+bool mel_normalize_batch(const float *raw, const MelUtt *utts, int n_utt, int n_mel, const unsigned *mel_max, float *out, int n_out, hipStream_t st);
 // The same frontend for one utterance without any allocation (PCM and result in the caller's device memory, the kernels'
 // intermediate data in a fixed device array of the library): at most kMelNoAllocMaxSamples samples in, n_out <=
 // kMelNoAllocMaxFramesOut frames out. mel_noalloc_init looks the array's device address up (once per device, that device

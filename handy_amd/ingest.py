@@ -3,7 +3,8 @@
 recordings in device memory, through the C ABI of libwhisper_mi355.so (`wmi_ingest_*`).  The per-frame speech probability
 (Silero in the reference, silero.rs:41-50) comes from the caller.
 
-Device memory comes from the HIP runtime the library itself is linked against (`DeviceBuffer`); anything else that exposes
+Device memory comes from the HIP runtime the library itself is linked against, through the library's own `wmi_dev_*`
+helpers (`DeviceBuffer`; no runtime is looked up by name here); anything else that exposes
 `data_ptr()` and `numel()` (a torch CUDA tensor, say) is accepted as input or as `out=` too -- the caller then passes the
 stream its data lives on."""
 import ctypes as C
@@ -16,19 +17,8 @@ from . import whisper_rs as wr
 WHISPER_SAMPLE_RATE = 16000
 FRAME_SAMPLES = 480         # 30 ms
 
-_hip = None
-
-
 def _runtime():
-    global _hip
-    if _hip is None:
-        wr.load_library()                              # the engine first: it brings in the runtime it was linked against
-        H = C.CDLL("libamdhip64.so.7")
-        H.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        H.hipFree.argtypes = [C.c_void_p]
-        H.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        _hip = H
-    return _hip
+    return wr.load_library()
 
 
 class DeviceBuffer:
@@ -37,24 +27,22 @@ class DeviceBuffer:
     def __init__(self, shape):
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         self.n = int(np.prod(self.shape)) if self.shape else 1
-        p = C.c_void_p()
-        rc = _runtime().hipMalloc(C.byref(p), max(self.n, 1) * 4)
-        if rc != 0 or not p.value:
-            raise wr.WhisperError(f"hipMalloc of {self.n * 4} bytes failed: {rc}")
-        self.ptr = p.value
+        self.ptr = _runtime().wmi_dev_alloc(max(self.n, 1) * 4)
+        if not self.ptr:
+            raise wr.WhisperError(f"device allocation of {self.n * 4} bytes failed")
 
     @classmethod
     def from_numpy(cls, a):
         a = np.ascontiguousarray(a, dtype=np.float32)
         b = cls(a.shape)
-        if a.size and _runtime().hipMemcpy(b.ptr, a.ctypes.data, a.nbytes, 1) != 0:
+        if a.size and _runtime().wmi_dev_upload(b.ptr, a.ctypes.data, a.nbytes) != 0:
             raise wr.WhisperError("hipMemcpy to the device failed")
         return b
 
     def numpy(self, n: Optional[int] = None) -> np.ndarray:
         """Copy back (waits for the null stream's work). n: only the first n floats, flat."""
         out = np.empty(self.shape if n is None else (int(n),), dtype=np.float32)
-        if out.size and _runtime().hipMemcpy(out.ctypes.data, self.ptr, out.nbytes, 2) != 0:
+        if out.size and _runtime().wmi_dev_download(out.ctypes.data, self.ptr, out.nbytes) != 0:
             raise wr.WhisperError("hipMemcpy from the device failed")
         return out
 
@@ -63,7 +51,7 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            _runtime().hipFree(self.ptr)
+            _runtime().wmi_dev_free(self.ptr)
             self.ptr = None
 
     def __del__(self):

@@ -5,7 +5,12 @@ src-tauri/src/managers/transcription.rs:39, :383); this module is what a bulk dr
 batch entry point."""
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+import base64
+import glob
+import json
+import os
+import zlib
+from typing import Dict, List, Optional, Sequence, Set
 
 import numpy as np
 
@@ -89,3 +94,83 @@ def gather_ragged_records(rec: np.ndarray, device=None) -> Optional[np.ndarray]:
     counts = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
     dist.all_gather(counts, n)
     return gather_token_records(rec, rows_per_rank=max(1, max(int(c.item()) for c in counts)), device=device)
+
+
+class ResultLog:
+    """Append-only log of the finished batches of one bulk job, one file per rank, so that a job of thousands of utterances
+    that dies at batch 39 of 40 resumes at batch 39 instead of losing the run (Handy itself only resumes model downloads:
+    reference src-tauri/src/managers/model.rs:361-405; it has no bulk job to resume).
+
+    One line per finished batch: {"job", "batch", "shape", "rec" (base64 of the int32 records), "crc"}, written with one
+    write call and fsync-ed before the batch counts as done. A torn or corrupt last line -- the crash happened inside the
+    write -- fails its JSON parse or its checksum and is ignored: that batch is simply run again. Lines of another job (a
+    different `job` key) are ignored as well. A rank owns its own file; files of ranks beyond the current world size (a resume
+    with fewer GPUs) are owned by rank 0, so every logged record is handed to the final gather exactly once."""
+
+    def __init__(self, directory: str, job: str, rank: int = 0, world: int = 1, resume: bool = True):
+        self.dir, self.job, self.rank, self.world = directory, job, int(rank), int(world)
+        os.makedirs(directory, exist_ok=True)
+        self.path = os.path.join(directory, f"rank{self.rank:04d}.jsonl")
+        if not resume and os.path.exists(self.path):
+            os.remove(self.path)
+        self._batches: Dict[int, np.ndarray] = {}     # finished batches whose records this rank owns
+        self._done: Set[int] = set()                  # finished batches of every rank
+        for f in sorted(glob.glob(os.path.join(directory, "rank*.jsonl"))) if resume else []:      # a fresh run reads nobody's old lines
+            try:
+                owner = int(os.path.basename(f)[4:8])
+            except ValueError:
+                continue
+            mine = owner == self.rank or (self.rank == 0 and owner >= self.world)
+            for b, rec in self._read(f):
+                if b in self._done and not (mine and b not in self._batches):
+                    continue
+                self._done.add(b)
+                if mine:
+                    self._batches[b] = rec
+        torn = False
+        if os.path.exists(self.path) and os.path.getsize(self.path) > 0:
+            with open(self.path, "rb") as fh:
+                fh.seek(-1, os.SEEK_END)
+                torn = fh.read(1) != b"\n"
+        self._fh = open(self.path, "ab")
+        if torn:                                       # the crash left half a line: the next record starts on a line of its own
+            self._fh.write(b"\n")
+
+    def _read(self, path: str):
+        try:
+            with open(path, "rb") as fh:
+                lines = fh.read().split(b"\n")
+        except OSError:
+            return
+        for line in lines:
+            if not line.strip():
+                continue
+            try:
+                d = json.loads(line)
+                raw = base64.b64decode(d["rec"])
+                if d["job"] != self.job or zlib.crc32(raw) != d["crc"]:
+                    continue
+                yield int(d["batch"]), np.frombuffer(raw, dtype=np.int32).reshape(d["shape"]).copy()
+            except (ValueError, KeyError, TypeError):
+                continue                              # a torn line: the batch it was about runs again
+
+    def done(self) -> Set[int]:
+        return set(self._done)
+
+    def records(self) -> List[np.ndarray]:
+        """Records of the logged batches this rank owns, in batch order."""
+        return [self._batches[b] for b in sorted(self._batches)]
+
+    def append(self, batch: int, rec: np.ndarray) -> None:
+        rec = np.ascontiguousarray(rec, dtype=np.int32)
+        raw = rec.tobytes()
+        line = json.dumps({"job": self.job, "batch": int(batch), "shape": list(rec.shape), "rec": base64.b64encode(raw).decode("ascii"),
+                           "crc": zlib.crc32(raw)}).encode("ascii") + b"\n"
+        self._fh.write(line)
+        self._fh.flush()
+        os.fsync(self._fh.fileno())
+        self._done.add(int(batch))
+        self._batches[int(batch)] = rec
+
+    def close(self) -> None:
+        self._fh.close()

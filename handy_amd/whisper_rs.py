@@ -132,11 +132,13 @@ whisper_full_get_token_text whisper_full_get_token_text_from_state whisper_full_
 whisper_full_get_token_data whisper_full_get_token_data_from_state whisper_full_get_token_p whisper_full_get_token_p_from_state
 wmi_init_state_batch wmi_full_batch wmi_batch_n_utts wmi_batch_n_segments wmi_batch_segment_t0 wmi_batch_segment_t1
 wmi_batch_segment_text wmi_batch_n_tokens wmi_batch_token_data wmi_batch_lang_id wmi_batch_n_fallbacks wmi_batch_rc
-wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_pcm_to_mel_device_noalloc wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
-wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_debug_quant_rows wmi_debug_enc_attention wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_set_quant_decode wmi_set_quant_resident wmi_set_decoder_lanes wmi_version
+wmi_set_force_tokens wmi_set_beam_candidates_sampled wmi_mel_batch_device wmi_mel_batch_device_normalized wmi_pcm_to_mel_device_noalloc wmi_get_mel wmi_get_encoder_output wmi_get_cross_kv
+wmi_decode_logits_all wmi_debug_gemm wmi_debug_gemm_gelu wmi_debug_expand_blocks wmi_debug_quant_rows wmi_debug_enc_attention wmi_set_window_cache wmi_get_window_cache_stats wmi_set_pipeline_groups wmi_set_encoder_lanes wmi_set_profiling wmi_set_profiling_classes wmi_get_kernel_stats wmi_reset_kernel_stats wmi_get_host_timings wmi_set_quant_decode wmi_set_quant_resident wmi_set_decoder_lanes wmi_set_pass_graphs wmi_version
 wmi_ingest_n_frames wmi_ingest_resample wmi_ingest_gate_plan wmi_ingest_gather
 wmi_ctx_for_device wmi_node_init wmi_node_free wmi_node_n_devices wmi_node_state wmi_node_context wmi_node_run wmi_node_last_gather
 wmi_node_last_batches wmi_node_run_custom
+wmi_dev_alloc wmi_dev_free wmi_dev_upload wmi_dev_download wmi_dev_memset wmi_dev_sync wmi_dev_free_bytes wmi_dev_stream_create
+wmi_dev_stream_sync wmi_dev_stream_destroy
 """.split()
 
 _lib = None
@@ -205,6 +207,7 @@ def load_library(path: Optional[str] = None):
     L.wmi_batch_rc.restype = ci; L.wmi_batch_rc.argtypes = [vp, ci]
     L.wmi_set_force_tokens.argtypes = [vp, ci]; L.wmi_set_beam_candidates_sampled.argtypes = [vp, ci]
     L.wmi_mel_batch_device.restype = ci; L.wmi_mel_batch_device.argtypes = [vp, vp, vp, C.POINTER(C.c_longlong), C.POINTER(ci), ci]
+    L.wmi_mel_batch_device_normalized.restype = ci; L.wmi_mel_batch_device_normalized.argtypes = [vp, vp, vp, C.POINTER(C.c_longlong), C.POINTER(ci), ci, vp, ci]
     L.wmi_pcm_to_mel_device_noalloc.restype = ci; L.wmi_pcm_to_mel_device_noalloc.argtypes = [vp, vp, ci, vp, ci, vp]
     L.wmi_get_mel.restype = ci; L.wmi_get_mel.argtypes = [vp, ci, fp, ci]
     L.wmi_get_encoder_output.restype = ci; L.wmi_get_encoder_output.argtypes = [vp, fp]
@@ -224,11 +227,23 @@ def load_library(path: Optional[str] = None):
     L.wmi_set_quant_decode.restype = ci; L.wmi_set_quant_decode.argtypes = [vp, ci]
     L.wmi_set_quant_resident.restype = None; L.wmi_set_quant_resident.argtypes = [ci]
     L.wmi_set_decoder_lanes.restype = ci; L.wmi_set_decoder_lanes.argtypes = [vp, ci]
+    L.wmi_set_pass_graphs.restype = None; L.wmi_set_pass_graphs.argtypes = [vp, ci]
     ll, llp = C.c_longlong, C.POINTER(C.c_longlong)
     L.wmi_ingest_n_frames.restype = ll; L.wmi_ingest_n_frames.argtypes = [ci, ll]
     L.wmi_ingest_resample.restype = ci; L.wmi_ingest_resample.argtypes = [vp, ll, ci, vp, ll, vp]
     L.wmi_ingest_gate_plan.restype = ll; L.wmi_ingest_gate_plan.argtypes = [C.POINTER(C.c_ubyte), ll, ci, ci, ci, llp, ll]
     L.wmi_ingest_gather.restype = ci; L.wmi_ingest_gather.argtypes = [vp, ll, llp, ll, vp, ll, llp, vp]
+    sz = C.c_size_t
+    L.wmi_dev_alloc.restype = vp; L.wmi_dev_alloc.argtypes = [sz]
+    L.wmi_dev_free.restype = None; L.wmi_dev_free.argtypes = [vp]
+    L.wmi_dev_upload.restype = ci; L.wmi_dev_upload.argtypes = [vp, vp, sz]
+    L.wmi_dev_download.restype = ci; L.wmi_dev_download.argtypes = [vp, vp, sz]
+    L.wmi_dev_memset.restype = ci; L.wmi_dev_memset.argtypes = [vp, ci, sz]
+    L.wmi_dev_sync.restype = ci; L.wmi_dev_sync.argtypes = []
+    L.wmi_dev_free_bytes.restype = ll; L.wmi_dev_free_bytes.argtypes = []
+    L.wmi_dev_stream_create.restype = vp; L.wmi_dev_stream_create.argtypes = []
+    L.wmi_dev_stream_sync.restype = ci; L.wmi_dev_stream_sync.argtypes = [vp]
+    L.wmi_dev_stream_destroy.restype = None; L.wmi_dev_stream_destroy.argtypes = [vp]
     if path is None:
         _lib = L
     return L
@@ -565,6 +580,9 @@ class WhisperState:
     def set_decoder_lanes(self, n: int):
         """Row lanes of a decoder pass (1 or 2 HIP streams)."""
         if self.L.wmi_set_decoder_lanes(self.h, int(n)) != 0: raise WhisperError("GenericError", -1)
+    def set_pass_graphs(self, on: bool):
+        """Decoder passes of a repeated shape replayed as HIP graphs (default on)."""
+        self.L.wmi_set_pass_graphs(self.h, 1 if on else 0)
     def set_quant_decode(self, on: bool):
         """Few-row decode passes read block-quantised decoder weights as blocks (default) or their fp16 copies."""
         if self.L.wmi_set_quant_decode(self.h, 1 if on else 0) != 0: raise WhisperError("GenericError", -1)

@@ -72,6 +72,14 @@ WHISPER_API void wmi_set_beam_candidates_sampled(struct whisper_state *state, in
 WHISPER_API int wmi_mel_batch_device(struct whisper_context *ctx, struct whisper_state *state, const float *pcm_dev,
                                      const long long *offsets, const int *n_samples, int n_utts);
 
+/* The same, ending in what whisper_pcm_to_mel leaves: the clamped and scaled log-mel ((max(x, max - 8) + 4) / 4, the maximum taken
+ * per utterance) of every utterance, written to the caller's device buffer mel_out_dev[n_utts][n_mel][n_frames_out] (float;
+ * n_frames_out a multiple of 4; frames past an utterance's audio carry the floor value). The whole frontend of
+ * whisper_pcm_to_mel_with_state for a batch already in device memory (reference call site: the engine behind
+ * src-tauri/src/managers/transcription.rs:413-415 computes it per clip on the CPU). */
+WHISPER_API int wmi_mel_batch_device_normalized(struct whisper_context *ctx, struct whisper_state *state, const float *pcm_dev,
+                                                const long long *offsets, const int *n_samples, int n_utts, float *mel_out_dev, int n_frames_out);
+
 /* The log-mel frontend for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc). No counterpart in the reference: it is whisper_pcm_to_mel_with_state() followed by
  * wmi_get_mel(), with the PCM (n_samples floats) and the result (normalised log-mel, [n_mel][n_frames_out] floats, frames
@@ -133,6 +141,10 @@ WHISPER_API void wmi_reset_kernel_stats(struct whisper_state *state);
  * half-size launches take as long as the full-size ones (they are bound by their own dependent chains) but did not overlap on
  * the boxes this was measured on. */
 WHISPER_API int wmi_set_decoder_lanes(struct whisper_state *state, int n);
+/* Decoder passes whose shape (rows, sequences, groups, audio context, ...) repeats are replayed as one HIP graph launch instead of
+ * the ten launches per layer they consist of; what differs between such passes travels in a metadata buffer the kernels read.
+ * Results are the same either way. On by default (WMI_PASS_GRAPHS=0 in the environment or on = 0 here turns it off). */
+WHISPER_API void wmi_set_pass_graphs(struct whisper_state *state, int on);
 WHISPER_API void wmi_set_quant_resident(int on);
 WHISPER_API int wmi_set_quant_decode(struct whisper_state *state, int on);
 WHISPER_API int wmi_get_host_timings(struct whisper_state *state, double *out /* [6] */);
@@ -167,6 +179,21 @@ WHISPER_API long long wmi_ingest_gate_plan(const unsigned char *is_voice, long l
  * is needed), -4 HIP error. */
 WHISPER_API int wmi_ingest_gather(const float *frames_dev, long long n_frames, const long long *src, long long n_src, float *out_dev,
                                   long long out_cap, long long *n_out, void *stream);
+
+/* ---- Device memory of the HIP runtime THIS library is linked against ---------------------------------------------------------
+ * For callers (ctypes, Rust) that have no HIP binding of their own and must not guess which copy of the runtime the library uses:
+ * a second runtime in one process (another ROCm major's soname, the copy a Python wheel carries) does not share its allocations.
+ * All act on the calling thread's current device. No counterpart in the reference (its callers hold host vectors). */
+WHISPER_API void *wmi_dev_alloc(size_t bytes);                                     /* hipMalloc; NULL on failure */
+WHISPER_API void wmi_dev_free(void *p);
+WHISPER_API int wmi_dev_upload(void *dst_dev, const void *src_host, size_t bytes); /* hipMemcpy (blocking); 0 ok */
+WHISPER_API int wmi_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+WHISPER_API int wmi_dev_memset(void *dst_dev, int byte, size_t bytes);
+WHISPER_API int wmi_dev_sync(void);                                                /* hipDeviceSynchronize */
+WHISPER_API long long wmi_dev_free_bytes(void);                                    /* hipMemGetInfo: free device memory, -1 on failure */
+WHISPER_API void *wmi_dev_stream_create(void);                                     /* a non-blocking hipStream_t; NULL on failure */
+WHISPER_API int wmi_dev_stream_sync(void *stream);
+WHISPER_API void wmi_dev_stream_destroy(void *stream);
 
 /* ---- Node level: one engine per GPU, data-parallel by utterance -----------------------------------------------------------
  * No counterpart in the reference (one engine behind one mutex: src-tauri/src/managers/transcription.rs:39, :383; the only

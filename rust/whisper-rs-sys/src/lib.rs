@@ -234,11 +234,14 @@ extern "C" {
     pub fn wmi_set_pipeline_groups(state: *mut whisper_state, n: c_int);
     pub fn wmi_set_encoder_lanes(state: *mut whisper_state, n: c_int) -> c_int;
     pub fn wmi_set_decoder_lanes(state: *mut whisper_state, n: c_int) -> c_int;
+    pub fn wmi_set_pass_graphs(state: *mut whisper_state, on: c_int);
     pub fn wmi_set_beam_candidates_sampled(state: *mut whisper_state, sampled: c_int);
     pub fn wmi_set_quant_resident(on: c_int);
     pub fn wmi_set_quant_decode(state: *mut whisper_state, on: c_int) -> c_int;
     pub fn wmi_mel_batch_device(ctx: *mut whisper_context, state: *mut whisper_state, pcm_dev: *const c_float, offsets: *const i64,
                                 n_samples: *const c_int, n_utts: c_int) -> c_int;
+    pub fn wmi_mel_batch_device_normalized(ctx: *mut whisper_context, state: *mut whisper_state, pcm_dev: *const c_float, offsets: *const i64,
+                                           n_samples: *const c_int, n_utts: c_int, mel_out_dev: *mut c_float, n_frames_out: c_int) -> c_int;
     /// The log-mel frontend without any allocation (callers under HIP graph capture, serving loops).
     pub fn wmi_pcm_to_mel_device_noalloc(ctx: *mut whisper_context, pcm_dev: *const c_float, n_samples: c_int, mel_out_dev: *mut c_float,
                                          n_frames_out: c_int, stream: *mut c_void) -> c_int;
@@ -263,6 +266,18 @@ extern "C" {
     pub fn wmi_debug_quant_rows(ggml_type: c_int, blocks: *const c_void, n: c_int, k: c_int, a_f16: *const u16, rows: c_int,
                                 out_blocks: *mut c_float, out_f16: *mut c_float) -> c_int;
     pub fn wmi_debug_enc_attention(b: c_int, h: c_int, t: c_int, q: *const u16, k: *const u16, v: *const u16, out: *mut u16) -> c_int;
+
+    // wmi.h: device memory of the HIP runtime the library is linked against (current device)
+    pub fn wmi_dev_alloc(bytes: usize) -> *mut c_void;
+    pub fn wmi_dev_free(p: *mut c_void);
+    pub fn wmi_dev_upload(dst_dev: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;
+    pub fn wmi_dev_download(dst_host: *mut c_void, src_dev: *const c_void, bytes: usize) -> c_int;
+    pub fn wmi_dev_memset(dst_dev: *mut c_void, byte: c_int, bytes: usize) -> c_int;
+    pub fn wmi_dev_sync() -> c_int;
+    pub fn wmi_dev_free_bytes() -> i64;
+    pub fn wmi_dev_stream_create() -> *mut c_void;
+    pub fn wmi_dev_stream_sync(stream: *mut c_void) -> c_int;
+    pub fn wmi_dev_stream_destroy(stream: *mut c_void);
 
     // wmi.h: node level -- one engine per GPU, data-parallel by utterance, result records gathered over RCCL
     pub fn wmi_ctx_for_device(path_model: *const c_char, device: c_int) -> *mut whisper_context;

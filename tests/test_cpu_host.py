@@ -210,6 +210,38 @@ def test_node_queue_hands_out_every_batch_once():
     assert lib.wmi_node_run_custom(2, 5, 0, fn_t(batch), None, recs, None) == -1
 
 
+def test_result_log_resumes_after_a_crash(tmp_path):
+    """The bulk job's append-only result log: finished batches survive the process, a line torn by a crash is ignored (its
+    batch runs again), another job's lines are not taken, and a resume with fewer ranks hands every logged record to the
+    gather exactly once."""
+    from handy_amd.node import ResultLog, pack_token_records
+    d = str(tmp_path / "log")
+    rec = lambda b: pack_token_records(range(4 * b, 4 * b + 4), [[b, 7, 50256]] * 4, 6)
+    a, c = ResultLog(d, "jobA", 0, 2, resume=False), ResultLog(d, "jobA", 1, 2, resume=False)
+    for b in (0, 2, 4):
+        a.append(b, rec(b))
+    for b in (1, 3):
+        c.append(b, rec(b))
+    a.close(); c.close()
+    with open(os.path.join(d, "rank0001.jsonl"), "ab") as f:      # the crash: half a line
+        f.write(b'{"job": "jobA", "batch": 5, "shape": [4, 8], "rec": "AAAA')
+    with open(os.path.join(d, "rank0000.jsonl"), "ab") as f:      # a line of some other job, and one with a bad checksum
+        f.write(b'{"job": "jobB", "batch": 6, "shape": [1, 1], "rec": "AAAAAA==", "crc": 558161692}\n')
+        f.write(b'{"job": "jobA", "batch": 7, "shape": [1, 1], "rec": "AAAAAA==", "crc": 1}\n')
+    r0, r1 = ResultLog(d, "jobA", 0, 2), ResultLog(d, "jobA", 1, 2)
+    assert r0.done() == r1.done() == {0, 1, 2, 3, 4}
+    assert [int(x[0, 0]) // 4 for x in r0.records()] == [0, 2, 4] and [int(x[0, 0]) // 4 for x in r1.records()] == [1, 3]
+    assert (r0.records()[1] == rec(2)).all()
+    r1.append(5, rec(5))                                           # the torn batch runs again and is logged after the torn bytes
+    r0.close(); r1.close()
+    solo = ResultLog(d, "jobA", 0, 1)                              # resume on one GPU: rank 0 takes over rank 1's file
+    assert solo.done() == {0, 1, 2, 3, 4, 5} and [int(x[0, 0]) // 4 for x in solo.records()] == [0, 1, 2, 3, 4, 5]
+    solo.close()
+    fresh = ResultLog(d, "jobA", 0, 1, resume=False)              # a fresh run forgets
+    assert fresh.done() == set() and fresh.records() == []
+    fresh.close()
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from handy_amd import whisper_rs as wr
     with pytest.raises(wr.WhisperError):

@@ -653,3 +653,34 @@ def test_one_bad_utterance_does_not_fail_the_batch(wr, model_path):
     with pytest.raises(wr.WhisperError):
         st.full_batch(fp2, pcms)
     st.free(); one.free(); ctx.free()
+
+
+@pytest.mark.parametrize("beam", [1, 3])
+def test_pass_graphs_do_not_change_results(wr, model_path, beam):
+    """Decoder passes of a repeated shape are replayed as HIP graphs (captured the second time a shape comes by). Tokens,
+    probabilities and segment times must be those of plain launches, bit for bit: a ragged greedy batch (shapes change as
+    utterances finish), beam search (page copies and row groups vary from pass to pass) and one clip step by step."""
+    path = model_path("micro", decisive=4.0)
+    ctx = wr.WhisperContext(path)
+    fp = wr.FullParams(wr.SamplingStrategy.BeamSearch(beam, -1.0) if beam > 1 else wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0); fp.set_language("en")
+    pcms = [synth_pcm(900 + i, int(16000 * s)) for i, s in enumerate((30.0, 6.0, 14.5, 30.0, 2.5, 21.0))]
+    outs = {}
+    for graphs in (False, True):
+        st = ctx.create_batch_state(len(pcms), beam, 4)
+        st.set_pass_graphs(graphs)
+        st.set_beam_candidates_sampled(False)
+        runs = []
+        for _ in range(2):                               # the second call replays what the first one captured
+            st.full_batch(fp, pcms)
+            runs.append([[(g.t0, g.t1, g.tokens, g.plog) for g in st.batch_segments(u)] for u in range(len(pcms))])
+        one = []
+        for pcm in pcms[:2]:
+            st.full_batch(fp, [pcm])
+            one.append([(g.t0, g.t1, g.tokens) for g in st.batch_segments(0)])
+        assert runs[0] == runs[1]
+        outs[graphs] = (runs[0], one)
+        st.free()
+    ctx.free()
+    assert outs[True] == outs[False]
+    assert sum(len(g[2]) for u in outs[True][0] for g in u) > 50

@@ -145,13 +145,19 @@ def test_turbo_encoder_chunk_size_does_not_change_results(wr, turbo_path):
         assert toks[136][u] == toks[136][u % 8]
 
 
-def test_large_v3_beam5_matches_oracle(wr, oracle, tmp_path_factory):
-    """Whisper large-v3 dimensions (32 encoder + 32 decoder layers, 128 mels), beam size 5 -- the decoder KV-cache and beam
-    path at its real depth -- on one clip against the oracle."""
+@pytest.fixture(scope="module")
+def v3_path(tmp_path_factory):
     from handy_amd import ggml_file as gf
-    from test_gpu_full import _run_pair, _same
     path = str(tmp_path_factory.mktemp("v3") / "synthetic-large-v3.bin")
     gf.write_synthetic_model(path, "large-v3", seed=1, decisive=2.0)
+    return path
+
+
+def test_large_v3_beam5_matches_oracle(wr, oracle, v3_path):
+    """Whisper large-v3 dimensions (32 encoder + 32 decoder layers, 128 mels), beam size 5 -- the decoder KV-cache and beam
+    path at its real depth -- on one clip against the oracle."""
+    from test_gpu_full import _run_pair, _same
+    path = v3_path
     fp = wr.FullParams(wr.SamplingStrategy.BeamSearch(5, -1.0))
     fp.set_temperature_inc(0.0); fp.set_language("en")
     pcms = [synth_pcm(35, int(21.0 * 16000))]
@@ -174,3 +180,122 @@ def test_small_models_greedy_batch_matches_oracle(wr, oracle, tmp_path_factory, 
     got, ref, _ = _run_pair(wr, oracle, path, fp, pcms, max_dec=1, force_n_tokens=14)
     for u in range(len(pcms)):
         assert _same(got[u], ref[u]), (u, [g.tokens for g in got[u]], [r["tokens"] for r in ref[u]])
+
+
+# ---- the benchmark's own shapes ----------------------------------------------------------------------------------------------
+# bench.py times 1024 utterances of large-v3-turbo per step (decoder passes of 1024 rows, encoder chunks of 128 = 192 000
+# activation rows through the persistent GEMM) and 64 utterances x beam 5 of large-v3 (320 rows in beam groups); its own
+# assertions only count tokens. These run those shapes once and check the results: copies of a clip agree wherever they sit,
+# a sample of the utterances equals what a batch of one gives, and (large-v3) two utterances equal the oracle.
+
+def test_headline_shape_1024_utterances(wr, turbo_path):
+    ctx = wr.WhisperContext(turbo_path)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0); fp.set_no_timestamps(True); fp.set_language("en")
+    n_force, n_clips, B = 16, 16, 1024
+    secs = [30.0] * 10 + [29.9, 17.3, 8.0, 3.0, 22.2, 12.0]
+    clips = [synth_pcm(300 + i, int(round(16000 * secs[i]))) for i in range(n_clips)]
+    order = list(np.random.default_rng(5).permutation(np.repeat(np.arange(n_clips), B // n_clips)))
+    st = ctx.create_batch_state(B, 1, 128)                       # the benchmark's encoder chunk
+    st.set_force_tokens(n_force)
+    st.full_batch(fp, [clips[i] for i in order])
+    toks = [list(st.batch_tokens(u)) for u in range(B)]
+    st.free()
+    first = {}
+    for u, c in enumerate(order):
+        assert len(toks[u]) == n_force + 1, (u, len(toks[u]))
+        if c in first:
+            assert toks[u] == toks[first[c]], f"copies of clip {c} at batch positions {first[c]} and {u} differ"
+        else:
+            first[c] = u
+    # (random weights repeat a token; which one depends on the audio: a handful of different streams among the 16 clips)
+    assert len({tuple(toks[first[c]]) for c in range(n_clips)}) >= 3, "every clip decodes to the same tokens: the check is blind"
+    st1 = ctx.create_batch_state(1, 1, 1)
+    st1.set_force_tokens(n_force)
+    for c in (0, 3, 7, 10, 11, 12, 13, 15):
+        st1.full_batch(fp, [clips[c]])
+        assert list(st1.batch_tokens(0)) == toks[first[c]], f"clip {c}: a batch of one differs from the batch of {B}"
+    st1.free(); ctx.free()
+
+
+def test_largev3_beam5_shape_64_utterances(wr, oracle, v3_path):
+    from test_gpu_full import _oracle_params, _same
+    ctx = wr.WhisperContext(v3_path)
+    fp = wr.FullParams(wr.SamplingStrategy.BeamSearch(5, -1.0))
+    fp.set_temperature_inc(0.0); fp.set_language("en")
+    n_force, B = 8, 64
+    secs = [30.0, 30.0, 21.0, 30.0, 9.5, 30.0, 29.9, 14.0]
+    clips = [synth_pcm(400 + i, int(round(16000 * s))) for i, s in enumerate(secs)]
+    order = list(np.random.default_rng(6).permutation(np.repeat(np.arange(len(clips)), B // len(clips))))
+    st = ctx.create_batch_state(B, 5, 64)
+    st.set_force_tokens(n_force); st.set_beam_candidates_sampled(False)
+    st.full_batch(fp, [clips[i] for i in order])
+    segs = [st.batch_segments(u) for u in range(B)]
+    st.free()
+    key = lambda sg: [(g.tokens, g.t0, g.t1) for g in sg]
+    first = {}
+    for u, c in enumerate(order):
+        if c in first:
+            assert key(segs[u]) == key(segs[first[c]]), f"copies of clip {c} at batch positions {first[c]} and {u} differ"
+        else:
+            first[c] = u
+    st1 = ctx.create_batch_state(1, 5, 1)
+    st1.set_force_tokens(n_force); st1.set_beam_candidates_sampled(False)
+    for c in range(len(clips)):
+        st1.full_batch(fp, [clips[c]])
+        assert key(st1.batch_segments(0)) == key(segs[first[c]]), f"clip {c}: a batch of one differs from the batch of {B}"
+    st1.free(); ctx.free()
+    om = oracle.OracleModel(v3_path); ost = oracle.OracleState(om)
+    op = _oracle_params(oracle, fp, force_n_tokens=n_force, beam_candidates_topk=1)
+    for c in (2, 4):                                              # the oracle needs ~10 s per large-v3 window: two clips
+        assert _same(segs[first[c]], ost.full(op, clips[c])), c
+    ost.close(); om.close()
+
+
+@pytest.mark.parametrize("arch", ["micro.en", "micro-v3"])
+def test_mel_batch_device_one_hour(wr, oracle, model_path, arch):
+    """wmi_mel_batch_device -- the entry point the log-mel benchmark configurations time -- on their workload, 120 x 30 s
+    already in device memory, 80 and 128 mel bins: the normalised log-mel of a sample of the utterances against the oracle
+    (the contract's 1e-3), and equal to what whisper_pcm_to_mel gives for the same clip."""
+    import ctypes as C
+    path = model_path(arch)
+    ctx = wr.WhisperContext(path)
+    B, n = 120, 30 * 16000
+    lens = [n] * B
+    lens[5], lens[77], lens[119] = 12345, 400000, 160                 # some shorter clips among them
+    clips = {u: synth_pcm(500 + u, lens[u]) for u in (0, 5, 42, 77, 118, 119)}
+    filler = synth_pcm(499, n)
+    L = ctx.L
+    dev = L.wmi_dev_alloc(B * n * 4)
+    assert dev
+    for u in range(B):
+        a = clips.get(u, filler[: lens[u]])
+        assert L.wmi_dev_upload(dev + u * n * 4, a.ctypes.data, a.nbytes) == 0
+    st = ctx.create_batch_state(B, 1, 16)
+    offs = (C.c_longlong * B)(*[u * n for u in range(B)]); ns = (C.c_int * B)(*lens)
+    assert L.wmi_mel_batch_device(ctx.h, st.h, C.c_void_p(dev), offs, ns, B) == 0
+    om = oracle.OracleModel(path); ost = oracle.OracleState(om)
+    st1 = ctx.create_state()
+    for u, pcm in clips.items():
+        ref = ost.pcm_to_mel(pcm)
+        got = st.get_mel(ref.shape[1], u)
+        assert np.isfinite(got).all()
+        err = float(np.abs(got - ref).max())
+        assert err <= 1e-3, (arch, u, err)
+        st1.pcm_to_mel(pcm)
+        assert np.array_equal(got, st1.get_mel(ref.shape[1])), (arch, u)
+    # the same call ending in the clamped, scaled log-mel of every utterance in the caller's buffer (what bench.py times)
+    n_mel, n_out = ctx.n_mels(), 3000
+    out_dev = L.wmi_dev_alloc(B * n_mel * n_out * 4 + 256)
+    assert out_dev and L.wmi_dev_memset(out_dev, 0xFF, B * n_mel * n_out * 4 + 256) == 0
+    assert L.wmi_mel_batch_device_normalized(ctx.h, st.h, C.c_void_p(dev), offs, ns, B, C.c_void_p(out_dev), n_out) == 0
+    for u in clips:
+        row = np.empty((n_mel, n_out), np.float32)
+        assert L.wmi_dev_download(row.ctypes.data, out_dev + u * n_mel * n_out * 4, row.nbytes) == 0
+        assert np.array_equal(row, st.get_mel(n_out, u)), (arch, u)
+    tail = np.empty(64, np.float32)
+    assert L.wmi_dev_download(tail.ctypes.data, out_dev + B * n_mel * n_out * 4, 256) == 0 and np.isnan(tail).all()     # nothing written past the result
+    assert L.wmi_mel_batch_device_normalized(ctx.h, st.h, C.c_void_p(dev), offs, ns, B, C.c_void_p(out_dev), 3001) == -1
+    L.wmi_dev_free(out_dev)
+    L.wmi_dev_free(dev)
+    st1.free(); st.free(); ctx.free(); ost.close(); om.close()
