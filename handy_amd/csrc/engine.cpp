@@ -1131,7 +1131,10 @@ int Engine::Run::run(const float *const *pcm, const int *n, int B, bool on_devic
         const int r = run_group(pcm, n, g0, std::min(E.max_utts_, B - g0), on_device);
         if (r != 0 && rc == 0) rc = r;
     }
-    if (single && rc == 0 && !P.no_context && !utts.empty()) E.carry_prompt_past = utts[0].prompt_past;
+    // whisper_full leaves the state's text context updated after every call, whatever no_context was (the flag only clears it at
+    // the start of a call): a call with no_context = false after one with no_context = true conditions on that call's text.
+    // A failed utterance leaves what was there.
+    if (single && rc == 0 && !utts.empty() && utts[0].rc == 0) E.carry_prompt_past = utts[0].prompt_past;
     return rc;
 }
 

@@ -44,7 +44,6 @@ __device__ __forceinline__ float gelu_f16_dev(float x) {
 
 struct EpiF16 {            // out[m][n] = f16(act((acc + bias) * scale))
     static constexpr bool kWide = true;
-    static constexpr int kStoresPerTile = 16;
     f16 *out; long ldc; const float *bias; int gelu; float scale;
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         if (bias) { const f32x4 b = *(const f32x4 *)(bias + n); a += b; }
@@ -72,7 +71,6 @@ struct EpiF16 {            // out[m][n] = f16(act((acc + bias) * scale))
 
 struct EpiF32 {            // out[m][n] = acc + bias
     static constexpr bool kWide = false;
-    static constexpr int kStoresPerTile = 32;
     float *out; long ldc; const float *bias;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a) const {
         if (bias) { const f32x4 b = *(const f32x4 *)(bias + n); a += b; }
@@ -83,7 +81,6 @@ struct EpiF32 {            // out[m][n] = acc + bias
 struct EpiResidual {       // x[m][n] += acc + bias   (fp32 residual stream, in place)
     static constexpr bool kWide = false;
     static constexpr bool kReadsOutput = true;      // load() early, apply() later: the staged epilogue hides the read's latency
-    static constexpr int kStoresPerTile = 32;
     float *x; long ldc; const float *bias;
     __device__ __forceinline__ f32x4 load(int m, int n) const { return *(const f32x4 *)(x + (long)m * ldc + n); }
     __device__ __forceinline__ void apply(int m, int n, f32x4 a, f32x4 r) const {
@@ -95,7 +92,6 @@ struct EpiResidual {       // x[m][n] += acc + bias   (fp32 residual stream, in 
 
 struct EpiConv1 {          // rows have period P = 2T+2 per utterance; h1[m+1][n] = t < 2T ? gelu(acc+b) : 0
     static constexpr bool kWide = true;
-    static constexpr int kStoresPerTile = 16;
     f16 *h1; int d; const float *bias; int period; int t_valid;
     __device__ __forceinline__ f16x4 value(int m, int n, f32x4 a) const {
         const int t = m % period;
@@ -127,7 +123,6 @@ struct EpiConv2 {          // rows have period T+1; x[b*T+t][n] = gelu(acc+b) + 
 
 struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d): K -> K[b][h][t][64]; [2d,3d): V -> Vt[b][h][64][enc_vt_pos(t)]
     static constexpr bool kWide = true;
-    static constexpr int kStoresPerTile = 16;
     f16 *Q, *K, *Vt; const float *bias; int d, H, T, Tp;
     int b0 = 0, base = 0;                   // begin_tile: utterance of the tile's first row, and that utterance's first row
     __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = m0 / T; base = b0 * T; }
@@ -177,8 +172,6 @@ struct EpiEncQKV {         // n in [0,d): Q*kEncQScale -> Q[b][h][t][64]; [d,2d)
 // T % 4 == 0: four consecutive columns never straddle two utterances.
 struct EpiVt {
     static constexpr bool kWide = true;
-    static constexpr int kStoresPerTile = 32;                                              // store8 is two store4
-    __device__ __forceinline__ bool tile_full(int m0, int n0, int M) const { return m0 + 256 <= M && n0 + 256 <= rows; }
     f16 *Vt; const float *bias; int H, T, Tp, rows;
     int b0 = 0, base = 0;                   // begin_tile: utterance of the tile's first column, and that utterance's first column
     __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = n0 / T; base = b0 * T; }
@@ -203,7 +196,6 @@ struct EpiVt {
 
 struct EpiCrossKV {        // n = (layer*2 + kv)*d + h*64 + e ; out[slot(b)][layer][kv][h][t][64]
     static constexpr bool kWide = true;
-    static constexpr int kStoresPerTile = 16;
     f16 *out; const float *bias; const int *slots; int d, H, T, Tp, n_layer;
     int b0 = -1, base = 0, lk0 = 0, nbase = 0;      // begin_tile: utterance / (layer, k|v) of the tile's first row / column
     __device__ __forceinline__ void begin_tile(int m0, int n0) { b0 = m0 / T; base = b0 * T; lk0 = n0 / d; nbase = lk0 * d; }
@@ -273,14 +265,6 @@ template <class Epi, class = void> struct epi_modes { static constexpr int value
 template <class Epi> struct epi_modes<Epi, decltype((void)Epi::kModes)> { static constexpr int value = Epi::kModes; };
 template <class Epi, class = void> struct has_begin_tile { static constexpr bool value = false; };
 template <class Epi> struct has_begin_tile<Epi, decltype((void)&Epi::begin_tile)> { static constexpr bool value = true; };
-// kStoresPerTile: global store instructions one wave issues in the staged epilogue of a tile whose every row (and, where the
-// epilogue looks at columns, column) is in range -- never more than it really issues. The persistent kernel counts them into
-// its first waits of the next tile (vmcnt is in issue order), so that those waits cover the half-tiles they are about and
-// not the acknowledgement of the epilogue's stores as well. 0: unknown, the waits cover everything.
-template <class Epi, class = void> struct stores_per_tile { static constexpr int value = 0; };
-template <class Epi> struct stores_per_tile<Epi, decltype((void)Epi::kStoresPerTile)> { static constexpr int value = Epi::kStoresPerTile; };
-template <class Epi, class = void> struct has_tile_full { static constexpr bool value = false; };
-template <class Epi> struct has_tile_full<Epi, decltype((void)&Epi::tile_full)> { static constexpr bool value = true; };
 template <class Epi, class = void> struct reads_output { static constexpr bool value = false; };
 template <class Epi> struct reads_output<Epi, decltype((void)Epi::kReadsOutput)> { static constexpr bool value = Epi::kReadsOutput; };
 
@@ -504,7 +488,7 @@ template <int MAXS, int LPS> __device__ __forceinline__ void wait_stages(int you
 // groups instead of in one burst after the barrier; kFirstHalf confines that to the first k-half of the step,
 // so the loads get the second half's MFMAs as extra time to land. Harness-only builds: kNoLoads / kNoLdsReads /
 // kNoMfma drop one ingredient of the loop (ablation timing), kStamps records s_memtime per loop section.
-enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128, kNoStagger = 256, kIssueFirst = 512, kVSplit = 1024, kOneTile = 2048, kNoRelax = 4096 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
+enum : int { kNoLoads = 1, kNoLdsReads = 2, kNoMfma = 4, kSpread = 8, kStamps = 16, kFirstHalf = 32, kSameTile = 64, kBufferLoad = 128, kNoStagger = 256, kIssueFirst = 512, kVSplit = 1024, kOneTile = 2048 };   // kSameTile: every workgroup loads tile (0,0): all L2 hits
 // kVSplit (product, 64x64 tile): the K loop is cut into slices of `vs` steps whose sums are added in slice order -- the very
 // additions the split-K path makes (one partial per slice, summed by its consumer), so the two paths agree bit for bit.
 
@@ -1031,13 +1015,10 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const f16 *__restrict__ 
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+    // Four half-tiles stay in flight behind every wait. Behind an epilogue the queue also holds that epilogue's stores, younger
+    // than half-tiles 2-5 of the new tile and older than what its phases issue; loads complete in order among themselves, so
+    // "at most 8 outstanding" still implies that the half-tile a phase is about to read has landed, whatever the stores do.
     using V8 = std::integral_constant<int, 8>;
-    // behind a full tile's epilogue the queue holds, in order: half-tiles 2-5 of this tile, the epilogue's stores, then what the
-    // phases issue; phase k of K-step 0 needs half-tile k + 2, so everything younger may stay in flight: 8 + the stores
-    constexpr int kEpiStores = (ABL & kNoRelax) ? 0 : stores_per_tile<Epi>::value;
-    using VR = std::integral_constant<int, 8 + kEpiStores>;
-    static_assert(8 + kEpiStores <= 63, "vmcnt is a 6-bit count");
-    bool relaxed = false;                                      // the previous tile's epilogue issued at least kEpiStores stores
 
     // the first tile's prologue: six half-tiles in flight, the first two landed (total >= 8)
 #pragma unroll
@@ -1058,10 +1039,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const f16 *__restrict__ 
         if (wr == 1) __builtin_amdgcn_s_barrier();             // waves 4-7 run one barrier behind
 
         const char *s0 = smem, *s1 = smem + 4 * SLOT;          // slots AL, BL, BH, AH of the even / odd K-steps
-        if (relaxed) { phase(I0{}, I0{}, VR{}, 0, s0); phase(I1{}, I0{}, VR{}, 0, s0); phase(I2{}, I0{}, VR{}, 0, s0); phase(I3{}, I0{}, VR{}, 0, s0); }
-        else { phase(I0{}, I0{}, V8{}, 0, s0); phase(I1{}, I0{}, V8{}, 0, s0); phase(I2{}, I0{}, V8{}, 0, s0); phase(I3{}, I0{}, V8{}, 0, s0); }
-        phase(I0{}, I0{}, V8{}, 1, s1); phase(I1{}, I0{}, V8{}, 1, s1); phase(I2{}, I0{}, V8{}, 1, s1); phase(I3{}, I0{}, V8{}, 1, s1);
-        for (int kt = 2; kt < nk - 2; kt += 2) {               // steady state: index p + 6 is of this tile, four half-tiles stay in flight
+        for (int kt = 0; kt < nk - 2; kt += 2) {               // steady state: index p + 6 is of this tile, four half-tiles stay in flight
             phase(I0{}, I0{}, V8{}, kt, s0); phase(I1{}, I0{}, V8{}, kt, s0); phase(I2{}, I0{}, V8{}, kt, s0); phase(I3{}, I0{}, V8{}, kt, s0);
             phase(I0{}, I0{}, V8{}, kt + 1, s1); phase(I1{}, I0{}, V8{}, kt + 1, s1); phase(I2{}, I0{}, V8{}, kt + 1, s1); phase(I3{}, I0{}, V8{}, kt + 1, s1);
         }
@@ -1084,8 +1062,6 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const f16 *__restrict__ 
         const int fr = lane_e & 15, fq = lane_e >> 4;
         const MapSplit map{wave_e >> 2, wave_e & 3};
         bool done = false;
-        if constexpr (has_tile_full<Epi>::value) relaxed = epi.tile_full(m0, n0, M);
-        else relaxed = m0 + 256 <= M;
         if constexpr (Epi::kWide) {
             if (epi.wide_block(n0, 256)) {
                 if constexpr (has_col_bias<Epi>::value && epi_modes<Epi>::value == 4) {
@@ -1103,7 +1079,6 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const f16 *__restrict__ 
             done = true;
         }
         if (!done) {
-            relaxed = false;
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -1134,14 +1109,14 @@ static int persistent_grid() {
 // tiles per workgroup from which the persistent kernel is used
 static bool persistent_ok(int M, int N, int K) {
     const int g = persistent_grid();
-    return g > 0 && N % 256 == 0 && K % (2 * BK) == 0 && K >= 4 * BK && (long)((M + 255) / 256) * (N / 256) >= 2L * g;
+    return g > 0 && N % 256 == 0 && K % (2 * BK) == 0 && K >= 2 * BK && (long)((M + 255) / 256) * (N / 256) >= 2L * g;
 }
 
 template <class Epi, int ABL = 0>
 static bool launch8p(const f16 *A, long lda, const f16 *W, long ldw, int M, int N, int K, const Epi &epi, hipStream_t st, int group_rows = 0) {
     if (M <= 0) return true;
     const int g = persistent_grid();
-    if (g <= 0 || N % 256 != 0 || K % (2 * BK) != 0 || K < 4 * BK) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (persistent 8-phase tile)\n", M, N, K); return false; }
+    if (g <= 0 || N % 256 != 0 || K % (2 * BK) != 0 || K < 2 * BK) { log_msg(2, "gemm: unsupported shape M=%d N=%d K=%d (persistent 8-phase tile)\n", M, N, K); return false; }
     const int nblk = ((M + 255) / 256) * (N / 256);
     constexpr size_t lds = 10 * 128 * 128;
     static std::atomic<unsigned long long> attr_set{0};
@@ -1236,7 +1211,6 @@ bool gemm_variant(int variant, const f16 *A, long lda, const f16 *W, long ldw, i
         case 60: return launch8p<EpiF16>(A, lda, W, ldw, M, N, K, e, st);                                      // persistent 8-phase kernel, plain f16 epilogue
         case 61: return launch8p<EpiResidual>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);
         case 62: return launch8p<EpiF16>(A, lda, W, ldw, M, N, K, EpiF16{out, ldc, (const float *)W, 1, 1.0f}, st);  // bias + GELU
-        case 65: return launch8p<EpiF16, kNoRelax>(A, lda, W, ldw, M, N, K, e, st);                            // ... its first waits of a tile also covering the epilogue's stores
         case 64: return launch8p<EpiF16, kOneTile>(A, lda, W, ldw, M, N, K, e, st);                            // the persistent kernel's loop, one tile per workgroup
         case 63: return launch8p<EpiF32>(A, lda, W, ldw, M, N, K, EpiF32{(float *)out, ldc, nullptr}, st);    // fp32 rows
         case 51: return launch8<EpiResidual>(A, lda, W, ldw, M, N, K, EpiResidual{(float *)out, ldc, (const float *)out}, st);

@@ -343,8 +343,10 @@ const DevicePlan *get_plan(int in_hz) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto key = std::make_pair(device, in_hz);
     auto it = g_plans.find(key);
-    if (it != g_plans.end()) return it->second.ok ? &it->second : nullptr;
-    DevicePlan &dp = g_plans[key];
+    if (it != g_plans.end()) return &it->second;
+    // built on the side and entered into the table only when every step has succeeded: a rate that cannot be supported is
+    // refused again next time by the same checks, and a transient failure (out of memory) does not stick to the rate
+    DevicePlan dp;
     ResamplePlan &p = dp.p;
     fft_sizes(in_hz, p.n_in, p.n_out);
     p.new_len = p.n_in > p.n_out ? p.n_out : p.n_in + 1;
@@ -369,7 +371,7 @@ const DevicePlan *get_plan(int in_hz) {
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) dp.n_cu = n_cu;
     dp.ok = true;
-    return &dp;
+    return &(g_plans[key] = dp);
 }
 
 // samples the resampler returns for n_in input samples (whole transform blocks of the input zero-padded to whole 1024-chunks)

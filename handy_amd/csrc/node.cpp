@@ -153,6 +153,11 @@ bool gather_rccl(const std::vector<int> &devices, const std::vector<std::vector<
     return ok;
 }
 
+bool distinct_or_single(const std::vector<int> &devs) {
+    for (size_t a = 0; a < devs.size(); a++) for (size_t b = a + 1; b < devs.size(); b++) if (devs[a] == devs[b]) return false;
+    return !devs.empty();
+}
+
 struct EngineJob {
     wmi_node *node;
     const whisper_full_params *params;
@@ -256,7 +261,8 @@ int wmi_node_run(wmi_node *node, struct whisper_full_params params, const float 
         bool distinct = n > 1;
         for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (node->devices[a] == node->devices[b]) distinct = false;
         const char *mode = getenv("WMI_NODE_GATHER");
-        if (distinct && !(mode && !strcmp(mode, "host")) && n_utts > 0) {
+        const bool force = mode && !strcmp(mode, "rccl") && distinct_or_single(node->devices);      // also with one GPU: a one-rank communicator (self-test)
+        if ((force || (distinct && !(mode && !strcmp(mode, "host")))) && n_utts > 0) {
             std::vector<std::vector<int>> rows(n);
             for (int u = 0; u < n_utts; u++) {
                 const int w = records_out[u].device;

@@ -174,3 +174,56 @@ class ResultLog:
 
     def close(self) -> None:
         self._fh.close()
+
+
+class NativeNode:
+    """The C-level node driver (include/wmi.h, wmi_node_*): one process, one engine and one worker thread per GPU pulling
+    batches from an atomic counter, result records gathered over RCCL. `devices=None`: every visible GPU."""
+
+    def __init__(self, path: str, devices: Optional[Sequence[int]] = None, batch: int = 256, max_decoders: int = 1, enc_chunk: int = 0):
+        import ctypes as C
+        from . import whisper_rs as wr
+        self._C, self._wr = C, wr
+        self.L = wr.load_library()
+        L = self.L
+        L.wmi_node_init.restype = C.c_void_p
+        L.wmi_node_init.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.wmi_node_free.restype = None; L.wmi_node_free.argtypes = [C.c_void_p]
+        L.wmi_node_n_devices.restype = C.c_int; L.wmi_node_n_devices.argtypes = [C.c_void_p]
+        L.wmi_node_state.restype = C.c_void_p; L.wmi_node_state.argtypes = [C.c_void_p, C.c_int]
+        L.wmi_node_run.restype = C.c_int
+        L.wmi_node_run.argtypes = [C.c_void_p, wr.whisper_full_params, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(wr.wmi_node_record)]
+        L.wmi_node_last_gather.restype = C.c_int; L.wmi_node_last_gather.argtypes = [C.c_void_p]
+        L.wmi_node_last_batches.restype = C.c_int; L.wmi_node_last_batches.argtypes = [C.c_void_p, C.c_int]
+        devs = (C.c_int * len(devices))(*devices) if devices else None
+        self.h = L.wmi_node_init(path.encode(), devs, len(devices) if devices else 0, batch, max_decoders, enc_chunk)
+        if not self.h:
+            raise wr.WhisperError("InitError: wmi_node_init failed")
+        self.n_devices = L.wmi_node_n_devices(self.h)
+
+    def set_force_tokens(self, n: int):
+        for i in range(self.n_devices):
+            self.L.wmi_set_force_tokens(self.L.wmi_node_state(self.h, i), int(n))
+
+    def run(self, params, pcm_list: Sequence[np.ndarray]):
+        """whisper_full over the clips, spread over the node's engines. Returns the list of wmi_node_record (utterance order)."""
+        C = self._C
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in pcm_list]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        ns = (C.c_int * len(arrs))(*[a.size for a in arrs])
+        recs = (self._wr.wmi_node_record * max(len(arrs), 1))()
+        rc = self.L.wmi_node_run(self.h, params.c, ptrs, ns, len(arrs), recs)
+        if rc != 0:
+            raise self._wr.WhisperError("GenericError: wmi_node_run", rc)
+        return [recs[i] for i in range(len(arrs))]
+
+    def last_gather(self) -> str:
+        return "rccl" if self.L.wmi_node_last_gather(self.h) == 1 else "host"
+
+    def batches_per_engine(self) -> List[int]:
+        return [self.L.wmi_node_last_batches(self.h, i) for i in range(self.n_devices)]
+
+    def free(self):
+        if self.h:
+            self.L.wmi_node_free(self.h)
+            self.h = None

@@ -14,7 +14,7 @@ for p in ("p1", "p2"):
     seen = set()
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = "enc_attention" if "enc_attention" in n else "gemm256_" + re.search(r"NS_\d+(Epi\w+?)ELi", n).group(1) if "gemm_nt_kernelILi256ELi256" in n else "layer_norm" if "layer_norm" in n else "cross_attn" if "dec_cross_attention" in n else None
+        k = "enc_attention" if "enc_attention" in n else "gemm256_" + re.search(r"NS_\d+(Epi\w+?)ELi", n).group(1) if ("gemm_nt_kernelILi256ELi256" in n or "gemm_nt8" in n) else "layer_norm" if "layer_norm" in n else "cross_attn" if "dec_cross_attention" in n else None
         if not k: continue
         res[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if p == "p1" and r["Counter_Name"] == "SQ_WAVE_CYCLES": cnt[k] += 1

@@ -18,9 +18,9 @@ def short(n):
     m = re.search(r"gemm_nt_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ENS_\d+(\w+?)ELi", n)
     if m:
         return f"gemm_nt<{m.group(1)}x{m.group(2)},{m.group(3)}>"
-    m = re.search(r"gemm_nt8_kernelINS_\d+(\w+?)ELi", n)
+    m = re.search(r"gemm_nt8(p?)_kernelINS_\d+(\w+?)ELi", n)
     if m:
-        return f"gemm_nt8<{m.group(1)}>"
+        return f"gemm_nt8{m.group(1)}<{m.group(2)}>"
     m = re.search(r"wmi\d*(\d\d)?([a-z_0-9]+_kernel)", n)
     m2 = re.search(r"wmi::([a-z_0-9]+)", n)
     return m2.group(1) if m2 else (m.group(2) if m else n[:40])

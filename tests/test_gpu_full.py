@@ -175,11 +175,15 @@ def test_greedy_streams_on_varied_weights(wr, oracle, model_path, arch):
         print(arch, "clip", i, f"streams part in window {w} at step {j}: engine {e_tok} oracle {o_tok}; rows differ by {err:.4f}; "
               f"oracle rules on the engine's row pick {picks[0]}, on its own row {picks[1]}")
         errs.append(err)
-        assert err <= 0.5, err
+        # observed over the 21 clips of the three architectures: 0.03, 0.03, 0.06, 0.09, 0.10, 0.15 and one 0.27 (micro, clip 5, step 79 of
+        # its window: 79 cached steps of fp16 K/V behind the row); the encoder output behind them is within 1.7e-3 of the oracle's
+        # (test_encoder_decoder_parity bounds it at 2.2e-3)
+        assert err <= 0.35, err
         if e_tok is not None and o_tok is not None:
             assert picks[0] == e_tok and picks[1] == o_tok, (picks, e_tok, o_tok)
     print(arch, "streams identical on", n_same, "of", len(secs), "clips;", n_tok, "oracle tokens")
     assert n_tok > 100
+    assert sum(e > 0.25 for e in errs) <= 1, errs
     if len(errs) >= 3:
         assert float(np.median(errs)) <= 0.15, errs
     st.free(); ctx.free(); ost.close(); om.close()
@@ -610,6 +614,13 @@ def test_text_context_carries_over_between_calls(wr, oracle, model_path):
     clean = [g.tokens for g in st.batch_segments(0)]
     assert _same(st.batch_segments(0), ost.full(op, b))
     assert clean != outs[1] or clean != outs[2], "the carried text context never changed a token"
+    # the flag clears the context at the START of a call only: a call with no_context = false after that one is conditioned on
+    # its text, and the call after it on both
+    fp.set_no_context(False); op.no_context = 0
+    for pcm in (a, b):
+        st.full(fp, pcm)
+        ref = ost.full(op, pcm)
+        assert _same(st.batch_segments(0), ref), ([g.tokens for g in st.batch_segments(0)], [r["tokens"] for r in ref])
     st.free(); ctx.free(); ost.close(); om.close()
 
 
@@ -684,3 +695,34 @@ def test_pass_graphs_do_not_change_results(wr, model_path, beam):
     ctx.free()
     assert outs[True] == outs[False]
     assert sum(len(g[2]) for u in outs[True][0] for g in u) > 50
+
+
+def test_node_driver_one_gpu(wr, model_path, monkeypatch):
+    """wmi_node_run on the one GPU of the test box: one engine; then two engines (two worker threads) on that same GPU, which
+    share the batch queue; then one engine with the records forced through a one-rank RCCL communicator (the library loads
+    librccl at that moment). Records must say what wmi_full_batch says for every clip, in utterance order, a failing clip
+    carrying its own code. (More than one distinct GPU -- the send / receive of the gather -- has not run anywhere.)"""
+    from handy_amd.node import NativeNode
+    path = model_path("micro", decisive=4.0)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language("auto")
+    secs = (30.0, 6.0, 14.5, 2.0, 21.0, 9.0, 30.0, 3.5, 12.0, 5.0, 17.0)
+    pcms = [synth_pcm(950 + i, int(16000 * s)) for i, s in enumerate(secs)]
+    pcms[4] = synth_pcm(999, 30)                     # too short for language detection: fails alone (-3)
+    ctx = wr.WhisperContext(path)
+    st = ctx.create_batch_state(len(pcms), 1, 4)
+    codes = st.full_batch(fp, pcms, allow_failed=True)
+    want = [(codes[u], st.batch_tokens(u), st.batch_lang_id(u) if codes[u] == 0 else None) for u in range(len(pcms))]
+    st.free(); ctx.free()
+    assert codes[4] == -3 and sum(len(t) for _, t, _ in want) > 50
+    for devices, gather in (([0], "host"), ([0, 0], "host"), ([0], "rccl")):
+        monkeypatch.setenv("WMI_NODE_GATHER", gather)
+        node = NativeNode(path, devices, batch=3, max_decoders=1, enc_chunk=2)
+        recs = node.run(fp, pcms)
+        assert node.last_gather() == gather, (devices, gather, node.last_gather())
+        assert sum(node.batches_per_engine()) == 4
+        for u, r in enumerate(recs):
+            assert r.utt == u and r.rc == want[u][0] and 0 <= r.device < len(devices)
+            assert list(r.tokens[: r.n_tokens]) == want[u][1], (devices, u)
+            if r.rc == 0:
+                assert r.lang_id == want[u][2] and r.n_segments >= 1 and r.t1 > r.t0 >= 0
+        node.free()

@@ -45,7 +45,7 @@ def test_turbo_one_utterance_matches_oracle(wr, oracle, turbo_path):
     err = float(np.abs(got - ref).max())
     print("turbo encoder: max abs err", err, "max |ref|", scale, "ref std", float(ref.std()))
     # fp16 GEMM operands and activations through 32 layers against the oracle's fp32 activations (fp16-rounded weights in both)
-    assert err <= 4e-3, (err, scale)                                               # observed 1.9e-3 at max |ref| 4.6; twice that
+    assert err <= 2.6e-3, (err, scale)                                             # observed 1.95e-3 at max |ref| 4.6; a third more
     kv_err = 0.0
     for layer in range(om.n_text_layer):
         k_ref, v_ref = ost.cross_kv(layer)

@@ -235,7 +235,10 @@ def test_encoder_decoder_parity(wr, oracle, golden, model_path, arch):
     got = st.encoder_output()
     err = np.abs(got - ref).max()
     print(arch, "encoder max abs err", err, "ref std", ref.std())
-    assert err <= 4e-3, err                                   # observed 1.4e-3 - 1.7e-3 (values are O(1)); twice that
+    # observed 1.65e-3 - 1.67e-3 on every test model (values are O(1)), with the first attention kernel and with the present one
+    # alike (scripts/diag_encoder_err.py). The bound leaves 30 %: a change of rounding in the encoder shows up here, not first
+    # in the greedy streams downstream.
+    assert err <= 2.2e-3, err
     if f"{arch}_enc" in golden:
         assert np.abs(got[::50] - golden[f"{arch}_enc"]).max() <= 8e-3       # transformers fp32 vs oracle 2.1e-3, plus the above
     kv_err = 0.0
