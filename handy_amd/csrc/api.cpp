@@ -550,6 +550,39 @@ void wmi_dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((
 #ifdef WMI_HARNESS       // benchmark harness entry points (libwhisper_mi355_harness.so only)
 int wmi_debug_read_gemm_stamps(unsigned long long *out, int n) { return wmi::gemm_read_stamps(out, n) ? 0 : -1; }
 void wmi_debug_set_tile_group(int rows) { if (rows >= 1) wmi::g_tile_group_rows = rows; }
+void wmi_debug_set_enc_attention(int variant) { wmi::enc_attention_set_variant(variant); }
+
+// Encoder attention alone: B utterances x H heads x T keys of random fp16 data, `iters` launches, average ms by HIP events.
+int wmi_bench_enc_attention(int B, int H, int T, int iters, float *ms_out) {
+    WMI_TRY
+    if (B <= 0 || H <= 0 || T <= 0 || T > 4096 || iters <= 0 || !ms_out) return -1;
+    const int Tp = round_up(T, 128);
+    const size_t n_pad = (size_t)B * H * Tp * 64, n_out = (size_t)B * T * H * 64;
+    std::vector<unsigned short> h(n_pad);
+    unsigned x = 12345u;
+    for (auto &e : h) { x = x * 1664525u + 1013904223u; e = (unsigned short)(0x3000u | ((x >> 9) & 0x83ffu)); }      // |v| in [0.125, 0.25), either sign
+    f16 *dq = nullptr, *dk = nullptr, *dvt = nullptr, *datt = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    if (hipMalloc(&dq, n_pad * 2) == hipSuccess && hipMalloc(&dk, n_pad * 2) == hipSuccess && hipMalloc(&dvt, n_pad * 2) == hipSuccess &&
+        hipMalloc(&datt, n_out * 2 + 256) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
+        hipMemcpy(dq, h.data(), n_pad * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dk, h.data(), n_pad * 2, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dvt, h.data(), n_pad * 2, hipMemcpyHostToDevice) == hipSuccess) {
+        bool ok = wmi::enc_attention(dq, dk, dvt, datt, B, H, T, Tp, nullptr) && wmi::enc_attention(dq, dk, dvt, datt, B, H, T, Tp, nullptr);
+        ok = ok && hipEventRecord(e0, nullptr) == hipSuccess;
+        for (int i = 0; ok && i < iters; i++) ok = wmi::enc_attention(dq, dk, dvt, datt, B, H, T, Tp, nullptr);
+        float ms = 0.0f;
+        if (ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+            *ms_out = ms / iters;
+            rc = 0;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    for (void *p : {(void *)dq, (void *)dk, (void *)dvt, (void *)datt}) (void)hipFree(p);
+    return rc;
+    WMI_CATCH(-1)
+}
 
 // GEMM tile-shape harness: random fp16 operands, `iters` launches of one variant, average ms by HIP events.
 int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out) {

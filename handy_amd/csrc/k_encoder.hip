@@ -1,4 +1,5 @@
 // Encoder-side kernels for gfx950: row LayerNorm and the non-causal multi-head attention.
+#include <atomic>
 #include "kernels.h"
 #include <type_traits>
 
@@ -398,6 +399,272 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
     }
 }
 
+
+#ifdef WMI_HARNESS
+// The same attention, software-pipelined inside each wave. Iteration t of a wave works on three key tiles at once: the matrix
+// pipe multiplies Q K^T of tile t + 1 and V^T P^T of tile t - 1 (16 MFMAs, none of which depends on anything this iteration
+// computes) while the vector pipe exponentiates tile t's scores (32 per lane: multiply, exponential, add, convert), the two
+// streams interleaved by hand -- one MFMA, then two scores' worth of vector work, pinned with scheduling barriers -- so that
+// the matrix pipe's 32 cycles per MFMA run under the vector instructions instead of beside another wave's. In the kernel above
+// that overlap depends on another wave of the SIMD being in the other phase, and the per-tile barrier keeps a workgroup's
+// waves in step. Costs a second set of score and probability registers (two waves per SIMD instead of three) and a third K
+// stage in LDS; V^T stays double-buffered (V^T of tile t is requested in iteration t and multiplied in t + 1).
+// The arithmetic is the kernel's above, operation for operation: same accumulation chains, same order of the partial sums,
+// and a tile that moves the reference m_run (rare) recomputes its own scores and those of the tile after it from the K tiles
+// still in the ring, with the new -m_run as the accumulators' starting value. The outputs are bit-identical.
+// ABL (harness only, wrong results): 1 no exponential, 2 no MFMA in the gaps, 3 no workgroup barrier, 4 no LDS fragment reads,
+// 5 no K / V^T staging, 6 staging never waited for, 7 = 2 + 5
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void enc_attention_pipe_kernel(const f16 *__restrict__ Q, const f16 *__restrict__ K, const f16 *__restrict__ Vt,
+                                                                    f16 *__restrict__ att, int H, int T, int Tp) {
+    __shared__ __attribute__((aligned(16))) char smem[5 * 8192];    // K tiles: 3 stages of 8 KB; V^T tiles: 2 stages of 8 KB
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nqb = Tp / 128, nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int qblk = logical % nqb, bh_i = logical / nqb;
+    if (qblk * 128 >= T) return;
+    const long bh = bh_i;
+    const int head = bh_i % H, b = bh_i / H;
+    const int q0 = qblk * 128 + wave * 32;
+    const f16 *qp = Q + (bh * Tp + q0 + r) * 64 + 8 * h;
+    f16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) qf[ks] = *(const f16x8 *)(qp + 16 * ks);
+    const f16 *kg = K + bh * Tp * 64;
+    const f16 *vg = Vt + bh * 64 * Tp;
+    const int srow = lane >> 3, sslot = lane & 7;
+    int koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = (wave + 4 * i) * 8 + srow, src_slot = sslot ^ ((row >> 1) & 7);
+        koff[i] = row * 64 + src_slot * 8;
+        voff[i] = row * Tp + src_slot * 8;
+    }
+    auto stage_k = [&](int kt, int slot) {
+        if (ABL == 5 || ABL == 7) return;
+        char *base = smem + slot * 8192 + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + (long)kt * 4096 + koff[i]),
+                                             (__attribute__((address_space(3))) void *)(base + i * 4096), 16, 0, 0);
+    };
+    auto stage_v = [&](int kt) {
+        if (ABL == 5 || ABL == 7) return;
+        char *base = smem + (3 + (kt & 1)) * 8192 + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + (long)kt * 64 + voff[i]),
+                                             (__attribute__((address_space(3))) void *)(base + i * 4096), 16, 0, 0);
+    };
+    auto stage_barrier = [&]() {
+        if (ABL != 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ABL != 3) __syncthreads();
+    };
+    // byte offset of this lane's fragment j (16-byte chunk 2 j + h, swizzled) inside its tile row: the same four offsets serve
+    // the K fragments (ks = j) and the V^T fragments (key chunk 2 j + h = 4 kh + 2 sidx + h); rows kh * 32 + r / blk * 32 + r
+    int foff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) foff[j] = r * 128 + (((2 * j + h) ^ ((r >> 1) & 7)) << 4);
+    f32x16 o0, o1, minit;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { o0[i] = 0.0f; o1[i] = 0.0f; minit[i] = 0.0f; }
+    float m_run = 0.0f, l_run = 0.0f;
+    const int n_tiles = (T + 63) / 64;
+    const bool ragged = (T & 63) != 0;
+    constexpr float kRedo = 32768.0f;
+    float lsum;
+
+    // scores of tile kt (its K in ring slot kt % 3) relative to the current reference, all at once: tile 0 and the rare path
+    auto scores = [&](f32x16 (&s)[2], int kt, int slot, bool mask) {
+        const char *kb = smem + slot * 8192;
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const f16x8 kf = *(const f16x8 *)(kb + kh * 4096 + foff[ks]);
+                if (ks == 0) s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], minit, 0, 0, 0);
+                else s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kh], 0, 0, 0);
+            }
+        if (mask) {
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int key = kt * 64 + kh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= T) s[kh][i] = -INFINITY;
+                }
+        }
+    };
+    auto exponentials = [&](const f32x16 (&s)[2], f16x8 (&pf)[2][2]) {
+        lsum = 0.0f;
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float p = __builtin_amdgcn_exp2f(s[kh][i] * kLog2e);
+                lsum += p;
+                pf[kh][i >> 3][i & 7] = (f16)p;
+            }
+    };
+    auto move_reference = [&](f32x16 (&s)[2], bool first) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[kh][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float delta = first ? mx : fmaxf(mx, 0.0f);
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[kh][i] -= delta;
+        m_run += delta;
+#pragma unroll
+        for (int i = 0; i < 16; i++) minit[i] = -m_run;
+        if (!first) {
+            const float alpha = __builtin_amdgcn_exp2f(-delta * kLog2e);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+    };
+    // the V^T P^T product of one tile, all at once: the last tile, after the loop
+    auto pv_all = [&](const f16x8 (&pf)[2][2], int kt) {
+        const char *vb = smem + (3 + (kt & 1)) * 8192;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f16x8 v0 = *(const f16x8 *)(vb + foff[j]), v1 = *(const f16x8 *)(vb + 4096 + foff[j]);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[j >> 1][j & 1], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[j >> 1][j & 1], o1, 0, 0, 0);
+        }
+    };
+
+    // One iteration, t >= 1: sixteen gaps, each one MFMA (first the eight of V^T P^T of tile t - 1, then the eight of Q K^T of
+    // tile t + 1), the LDS read of the fragment three MFMAs ahead, and two of tile t's scores; nothing crosses a gap boundary.
+    // The last iteration multiplies a tile t + 1 that does not exist (whatever its ring slot holds; the scores are never looked
+    // at): 8 of a wave's ~400 MFMAs, cheaper than a second copy of the loop body.
+    auto body = [&](int t, int slot_cur, int slot_nxt, f32x16 (&sc)[2], f32x16 (&sn)[2], f16x8 (&pfp)[2][2], f16x8 (&pfc)[2][2]) {
+        const char *kb = smem + slot_nxt * 8192;
+        const char *vb = smem + (3 + ((t - 1) & 1)) * 8192;
+        // fragment of MFMA g: g < 8: V^T rows (g & 1) * 32 + r, key chunk pair g >> 1; g >= 8: K rows ((g - 8) >> 2) * 32 + r, ks = g & 3
+        f16x8 frag[16];
+        auto fetch = [&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            if constexpr (ABL == 4) { if constexpr (g < 16) frag[g] = qf[g & 3]; }
+            else if constexpr (g < 8) frag[g] = *(const f16x8 *)(vb + (g & 1) * 4096 + foff[g >> 1]);
+            else if constexpr (g < 16) frag[g] = *(const f16x8 *)(kb + ((g - 8) >> 2) * 4096 + foff[g & 3]);
+        };
+        auto gap = [&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            if constexpr (ABL == 2 || ABL == 7) {
+                if constexpr (g < 8) o0[g] += (float)frag[g][0]; else sn[(g - 8) >> 2][g & 3] = (float)frag[g][0];
+            } else if constexpr (g < 8) {
+                if constexpr (g & 1) o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag[g], pfp[g >> 2][(g >> 1) & 1], o1, 0, 0, 0);
+                else o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag[g], pfp[g >> 2][(g >> 1) & 1], o0, 0, 0, 0);
+            } else {
+                constexpr int kh = (g - 8) >> 2, ks = g & 3;
+                if constexpr (ks == 0) sn[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag[g], qf[ks], minit, 0, 0, 0);
+                else sn[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag[g], qf[ks], sn[kh], 0, 0, 0);
+            }
+            fetch(std::integral_constant<int, g + 3>{});
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                constexpr int kh = g >> 3;
+                const int i = (2 * g + e) & 15;
+                const float p = ABL == 1 ? sc[kh][i] * kLog2e : __builtin_amdgcn_exp2f(sc[kh][i] * kLog2e);
+                lsum += p;
+                pfc[kh][i >> 3][i & 7] = (f16)p;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (t + 2 < n_tiles) stage_k(t + 2, slot_cur == 0 ? 2 : slot_cur - 1);         // the slot tile t - 1 has left
+        stage_v(t);
+        lsum = 0.0f;
+        fetch(std::integral_constant<int, 0>{}); fetch(std::integral_constant<int, 1>{}); fetch(std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        gap(std::integral_constant<int, 0>{}); gap(std::integral_constant<int, 1>{}); gap(std::integral_constant<int, 2>{});
+        gap(std::integral_constant<int, 3>{}); gap(std::integral_constant<int, 4>{}); gap(std::integral_constant<int, 5>{});
+        gap(std::integral_constant<int, 6>{}); gap(std::integral_constant<int, 7>{}); gap(std::integral_constant<int, 8>{});
+        gap(std::integral_constant<int, 9>{}); gap(std::integral_constant<int, 10>{}); gap(std::integral_constant<int, 11>{});
+        gap(std::integral_constant<int, 12>{}); gap(std::integral_constant<int, 13>{}); gap(std::integral_constant<int, 14>{});
+        gap(std::integral_constant<int, 15>{});
+        // the probabilities and their sum exist here, not wherever their first reader is (code sinking would carry the
+        // exponentials out of the gaps, into the blocks after the branches below)
+        asm volatile("" : "+v"(lsum), "+v"(pfc[0][0]), "+v"(pfc[0][1]), "+v"(pfc[1][0]), "+v"(pfc[1][1]));
+        const bool mask_next = ragged && t + 2 == n_tiles;
+        if (mask_next) {
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int key = (t + 1) * 64 + kh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= T) sn[kh][i] = -INFINITY;
+                }
+        }
+        if (__builtin_amdgcn_ballot_w64(lsum >= kRedo) != 0) {               // wave-uniform, rare
+            asm volatile("" ::: "memory");
+            scores(sc, t, slot_cur, ragged && t + 1 == n_tiles);
+            move_reference(sc, false);
+            exponentials(sc, pfc);
+            if (t + 1 < n_tiles) scores(sn, t + 1, slot_nxt, mask_next);
+        }
+        l_run += lsum;
+        stage_barrier();
+    };
+
+    // tile 0 sets the reference; its exponentials and tile 1's scores one after the other
+    stage_k(0, 0);
+    if (n_tiles > 1) stage_k(1, 1);
+    stage_v(0);
+    stage_barrier();
+    f32x16 sa[2], sb[2];
+    f16x8 pa[2][2], pb[2][2];
+    scores(sa, 0, 0, ragged && n_tiles == 1);
+    move_reference(sa, true);
+    if (n_tiles > 2) stage_k(2, 2);
+    if (n_tiles > 1) scores(sb, 1, 1, ragged && n_tiles == 2);
+    exponentials(sa, pa);
+    l_run += lsum;
+    stage_barrier();
+    // iteration t: K of tile t in ring slot t % 3. Odd t: scores in sb, probabilities into pb; even t: sa, pa.
+    int t = 1, slot = 1;
+    for (; t + 1 < n_tiles; t += 2) {
+        body(t, slot, slot == 2 ? 0 : slot + 1, sb, sa, pa, pb);
+        slot = slot == 2 ? 0 : slot + 1;
+        body(t + 1, slot, slot == 2 ? 0 : slot + 1, sa, sb, pb, pa);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (t < n_tiles) {
+        body(t, slot, slot == 2 ? 0 : slot + 1, sb, sa, pa, pb);
+        pv_all(pb, t);
+    } else {
+        pv_all(pa, n_tiles - 1);
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    char *ob = smem;
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x16 &o = blk ? o1 : o0;
+            const f16x4 v4 = {(f16)(o[4 * g] * inv), (f16)(o[4 * g + 1] * inv), (f16)(o[4 * g + 2] * inv), (f16)(o[4 * g + 3] * inv)};
+            const int orow = wave * 32 + r;
+            *(f16x4 *)(ob + orow * 128 + (((4 * blk + g) ^ (orow & 7)) << 4) + 8 * h) = v4;
+        }
+    __syncthreads();
+    const int d = H * 64;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int idx = p * 256 + tid, row = idx >> 3, ch = idx & 7, q = qblk * 128 + row;
+        if (q < T) *(f16x8 *)(att + ((long)b * T + q) * d + head * 64 + ch * 8) = *(const f16x8 *)(ob + row * 128 + ((ch ^ (row & 7)) << 4));
+    }
+}
+
+#endif  // WMI_HARNESS (enc_attention_pipe_kernel)
+
 #ifdef WMI_HARNESS
 // Micro-benchmark (harness only): time of 16-byte LDS writes / reads (four per iteration, 8 workgroups per CU) under a lane ->
 // (row, slot) pattern; rows are 128 bytes.
@@ -447,10 +714,26 @@ bool lds_pattern_bench(int pattern, int do_read, int iters, float *ms_out) {
 
 #endif  // WMI_HARNESS
 
+#ifdef WMI_HARNESS
+// which attention kernel enc_attention() launches in the harness library: 0 enc_attention_kernel, 1 enc_attention_pipe_kernel,
+// 11..17 its ablations (WMI_ENC_ATTN at load, wmi_debug_set_enc_attention afterwards)
+std::atomic<int> g_enc_attention_variant{[] { const char *e = getenv("WMI_ENC_ATTN"); return e ? atoi(e) : 0; }()};
+void enc_attention_set_variant(int v) { g_enc_attention_variant.store(v, std::memory_order_relaxed); }
+#endif
+
 bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st) {
     if (B <= 0) return true;
     if (Tp % 128 != 0 || T > Tp) { log_msg(2, "enc_attention: bad padding T=%d Tp=%d\n", T, Tp); return false; }
-    hipLaunchKernelGGL(enc_attention_kernel, dim3((Tp / 128) * H * B), dim3(256), 0, st, Q, K, Vt, att, H, T, Tp);
+    const dim3 grid((Tp / 128) * H * B);
+#ifdef WMI_HARNESS
+    switch (g_enc_attention_variant.load(std::memory_order_relaxed)) {
+#define WMI_PIPE(V_, A_) case V_: hipLaunchKernelGGL(enc_attention_pipe_kernel<A_>, grid, dim3(256), 0, st, Q, K, Vt, att, H, T, Tp); return hipGetLastError() == hipSuccess;
+        WMI_PIPE(1, 0) WMI_PIPE(11, 1) WMI_PIPE(12, 2) WMI_PIPE(13, 3) WMI_PIPE(14, 4) WMI_PIPE(15, 5) WMI_PIPE(16, 6) WMI_PIPE(17, 7)
+#undef WMI_PIPE
+        default: break;
+    }
+#endif
+    hipLaunchKernelGGL(enc_attention_kernel, grid, dim3(256), 0, st, Q, K, Vt, att, H, T, Tp);
     return hipGetLastError() == hipSuccess;
 }
 

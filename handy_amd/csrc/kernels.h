@@ -97,6 +97,9 @@ bool layer_norm_variant(int variant, const float *x, const float *w, const float
 bool layer_norm(const float *x, const float *w, const float *b, f16 *out16, float *out32, int M, int d, const int *gather, hipStream_t st);
 // non-causal attention over T keys (padded to Tp), heads of 64: Q,K [B][H][Tp][64], Vt [B][H][64][Tp] with key t at enc_vt_pos(t) -> att [B*T][H*64]
 bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st);
+#ifdef WMI_HARNESS
+void enc_attention_set_variant(int v);   // harness: 0 enc_attention_kernel, 1 enc_attention_pipe_kernel, 11..17 its ablations
+#endif
 
 // ---- k_decoder.hip --------------------------------------------------------------------------
 bool dec_embed(const f16 *te, const float *pe, const DecRow *rows, int M, int d, float *x, hipStream_t st);

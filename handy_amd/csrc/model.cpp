@@ -289,22 +289,4 @@ Model *load_model(const uint8_t *data, size_t size, int device) {
     return M.release();
 }
 
-// Greedy longest-match over the vocabulary, preferring a leading-space form at word starts.
-std::vector<int> tokenize(const Vocab &v, const std::string &text) {
-    std::vector<int> out;
-    size_t i = 0;
-    size_t max_len = 0;
-    for (const auto &kv : v.token_to_id) max_len = std::max(max_len, kv.first.size());
-    while (i < text.size()) {
-        size_t best = 0; int id = -1;
-        for (size_t l = std::min(max_len, text.size() - i); l > 0; l--) {
-            auto it = v.token_to_id.find(text.substr(i, l));
-            if (it != v.token_to_id.end() && it->second < v.eot) { best = l; id = it->second; break; }
-        }
-        if (id < 0) { i++; continue; }
-        out.push_back(id); i += best;
-    }
-    return out;
-}
-
 }  // namespace wmi

@@ -50,7 +50,5 @@ void set_quant_resident(bool on);
 bool quant_resident();
 
 
-// greedy longest-match tokenizer over the model vocabulary (initial_prompt support)
-std::vector<int> tokenize(const Vocab &v, const std::string &text);
 
 }  // namespace wmi

@@ -220,4 +220,57 @@ bool check_model_tensors(const ParsedFile &F) {
     return ok;
 }
 
+// whisper.cpp's tokenize() (whisper.cpp, "static std::vector<whisper_vocab::id> tokenize", as recalled: the pinned source is
+// not in the reference tree): the text is cut into words by the GPT-2 pre-tokenisation pattern
+//   's|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s[:alpha:][:digit:]]+|\s+(?!\S)|\s+
+// (std::regex, ECMAScript, "C" locale: classes are ASCII, bytes >= 0x80 are neither letters nor digits nor space), and every
+// word is covered left to right by the longest vocabulary entries; a byte no entry starts at is skipped. The pattern is
+// scanned by hand here: ordered alternatives, first match wins, and every byte starts some match, so the words tile the text.
+// Control tokens (ids >= eot) are never produced from text.
+namespace {
+inline bool is_space(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+inline bool is_alpha(unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+inline bool is_digit(unsigned char c) { return c >= '0' && c <= '9'; }
+inline bool is_other(unsigned char c) { return !is_space(c) && !is_alpha(c) && !is_digit(c); }
+
+size_t next_word_len(const std::string &t, size_t i) {
+    const size_t n = t.size();
+    if (t[i] == '\'') {
+        static const char *const k_contractions[] = {"'s", "'t", "'re", "'ve", "'m", "'ll", "'d"};
+        for (const char *c : k_contractions) {
+            const size_t l = strlen(c);
+            if (t.compare(i, l, c) == 0) return l;
+        }
+    }
+    bool (*const classes[3])(unsigned char) = {is_alpha, is_digit, is_other};
+    for (auto in_class : classes) {
+        size_t j = i + (t[i] == ' ' && i + 1 < n && in_class((unsigned char)t[i + 1]) ? 1 : 0);
+        const size_t first = j;
+        while (j < n && in_class((unsigned char)t[j])) j++;
+        if (j > first) return j - i;
+    }
+    size_t j = i;                                   // only white space starts here
+    while (j < n && is_space((unsigned char)t[j])) j++;
+    if (j < n && j - i > 1) return j - i - 1;       // \s+(?!\S): leave the last one to the word that follows
+    return j - i;                                   // the run reaches the end of the text, or is a single character: \s+
+}
+}  // namespace
+
+std::vector<int> tokenize(const Vocab &v, const std::string &text) {
+    std::vector<int> out;
+    for (size_t w = 0; w < text.size();) {
+        const size_t wl = next_word_len(text, w);
+        for (size_t i = w; i < w + wl;) {
+            size_t j = w + wl;
+            for (; j > i; j--) {
+                const auto it = v.token_to_id.find(text.substr(i, j - i));
+                if (it != v.token_to_id.end() && it->second < v.eot) { out.push_back(it->second); break; }
+            }
+            i = j > i ? j : i + 1;
+        }
+        w += wl;
+    }
+    return out;
+}
+
 }  // namespace wmi

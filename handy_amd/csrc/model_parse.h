@@ -58,4 +58,8 @@ bool parse_model_file(const uint8_t *data, size_t size, ParsedFile &out);
 // Every tensor the engine reads exists with the element count the hyper-parameters imply.
 bool check_model_tensors(const ParsedFile &f);
 
+// Text -> token ids as whisper.cpp's tokenize() does it (initial_prompt, whisper_tokenize): words by the GPT-2 pattern, each
+// covered by the longest vocabulary entries.
+std::vector<int> tokenize(const Vocab &v, const std::string &text);
+
 }  // namespace wmi

@@ -4,6 +4,7 @@
 //   trunc N               only the first N bytes
 //   set32 OFFSET VALUE    a little-endian 32-bit word replaced
 //   flip OFFSET BIT       one bit flipped
+//   tok HEX               tokenises the text whose bytes are HEX with the (unmodified) file's vocabulary: "tok HEX -> count id id ..."
 // Prints "<mutation> -> ok <tensors>" or "-> rejected" per line; a memory error or undefined behaviour ends the process
 // through the sanitizers instead.
 #include <stdarg.h>
@@ -28,12 +29,24 @@ int main(int argc, char **argv) {
     std::vector<unsigned char> img((size_t)f.tellg());
     f.seekg(0);
     f.read((char *)img.data(), (std::streamsize)img.size());
-    char line[256];
+    char line[4096];
     while (fgets(line, sizeof line, stdin)) {
         line[strcspn(line, "\n")] = 0;
         char op[16] = {0};
         long long a = 0, b = 0;
         if (sscanf(line, "%15s %lld %lld", op, &a, &b) < 1) continue;
+        if (!strcmp(op, "tok")) {
+            wmi::ParsedFile F;
+            if (!wmi::parse_model_file(img.data(), img.size(), F)) { printf("%s -> rejected\n", line); continue; }
+            std::string text;
+            const char *hex = strchr(line, ' ');
+            for (hex = hex ? hex + 1 : ""; hex[0] && hex[1]; hex += 2) { unsigned v = 0; sscanf(hex, "%2x", &v); text.push_back((char)v); }
+            const std::vector<int> ids = wmi::tokenize(F.vocab, text);
+            printf("%s -> %zu", line, ids.size());
+            for (int id : ids) printf(" %d", id);
+            printf("\n");
+            continue;
+        }
         size_t n = img.size();
         if (!strcmp(op, "trunc")) n = (size_t)(a < 0 ? 0 : ((size_t)a > img.size() ? img.size() : (size_t)a));
         // an exact-size heap copy: reading one byte past the end of the (possibly truncated) image is an ASan report

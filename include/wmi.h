@@ -117,6 +117,8 @@ WHISPER_API int wmi_debug_gemm_variant_diff(int M, int N, int K, int variant, in
 WHISPER_API int wmi_bench_lds_pattern(int pattern, int do_read, int iters, float *ms_out);                /* 16-byte LDS access patterns, one workgroup per CU (harness) */
 WHISPER_API int wmi_bench_layer_norm(int M, int d, int variant, int iters, float *ms_out);            /* LayerNorm A/B harness (variant 100 = the shipped kernel) */
 WHISPER_API int wmi_bench_gemm(int M, int N, int K, int variant, int iters, float *ms_out);            /* tile-shape A/B harness, random fp16 operands */
+WHISPER_API void wmi_debug_set_enc_attention(int variant);                                              /* harness knob: 0 enc_attention_kernel, 1 enc_attention_pipe_kernel */
+WHISPER_API int wmi_bench_enc_attention(int B, int H, int T, int iters, float *ms_out);                  /* encoder attention alone, random fp16 data (harness) */
 #endif
 
 /* Per-kernel-class device time, measured with HIP events on the engine's stream. */

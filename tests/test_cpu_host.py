@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 HARNESS_ONLY = {"wmi_bench_gemm", "wmi_bench_layer_norm", "wmi_bench_lds_pattern", "wmi_debug_set_tile_group", "wmi_debug_read_gemm_stamps",
-                "wmi_debug_gemm_variant_diff"}
+                "wmi_debug_gemm_variant_diff", "wmi_debug_set_enc_attention", "wmi_bench_enc_attention"}
 
 
 def _declared_in_headers():

@@ -100,3 +100,54 @@ def test_oracle_under_sanitizers(micro_model):
         g.write(f.read(os.path.getsize(micro_model) // 2))
     r = subprocess.run([os.path.join(ROOT, "oracle", "_san", "oracle_san"), cut], text=True, capture_output=True, env=SAN_ENV, timeout=300)
     assert r.returncode == 3, f"exit {r.returncode}\n{r.stdout}\n{r.stderr[-3000:]}"
+
+
+def test_tokenizer_follows_the_word_pattern(micro_model):
+    """`whisper_tokenize` / `initial_prompt`: whisper.cpp cuts the text into words with the GPT-2 pre-tokenisation pattern and
+    covers each word with the longest vocabulary entries (no merge ranks). The engine scans that pattern by hand
+    (model_parse.cpp); here the same pattern goes through Python's `re` on bytes and the two must agree token for token, on text
+    with contractions, digits, punctuation, white-space runs, tabs, UTF-8 and words that only exist with a leading space.
+    Parity unpinned: whisper.cpp's source is not in the reference tree, the pattern and the loop are as recalled."""
+    import re
+    from handy_amd import ggml_file
+    m = ggml_file.read_model(micro_model) if hasattr(ggml_file, "read_model") else None
+    vocab = m.vocab if m is not None else ggml_file.synthetic_vocab(ggml_file.n_file_tokens(ggml_file.hparams_for("micro")))
+    ids = {}
+    for i, t in enumerate(vocab):
+        ids[t] = i
+    pat = re.compile(rb"'s|'t|'re|'ve|'m|'ll|'d| ?[A-Za-z]+| ?[0-9]+| ?[^\sA-Za-z0-9]+|\s+(?!\S)|\s+")
+
+    def expected(text):
+        out = []
+        for w in pat.findall(text):
+            i = 0
+            while i < len(w):
+                for j in range(len(w), i, -1):
+                    if w[i:j] in ids:
+                        out.append(ids[w[i:j]]); i = j
+                        break
+                else:
+                    i += 1
+        return out
+
+    words = [t for t in vocab[256:400]]
+    rng = np.random.default_rng(5)
+    texts = [b"", b" ", b"  ", b"a", b"it's the kato's", b"we'll they've I'm you'd can't 're", b"12 345  6789", b"  lead and trail  ", b"tab\tsep\n\nnew  \t line",
+             b"semi;colon -- dash...", "café naïve 日本".encode(), b"'", b"''s", b"x'sy", b" 'll", b"a  b   c    d", b"end with space \t"]
+    for _ in range(40):
+        parts = []
+        for _ in range(int(rng.integers(1, 9))):
+            k = int(rng.integers(0, 6))
+            parts.append([words[int(rng.integers(len(words)))], words[int(rng.integers(len(words)))].strip() + b"'s", str(int(rng.integers(0, 99999))).encode(),
+                          bytes(rng.choice(list(b" \t\n.,;!?-'\""), int(rng.integers(1, 4))).tolist()), b" ", bytes([int(rng.integers(128, 256))])][k])
+        texts.append(b"".join(parts))
+    muts = list(dict.fromkeys(("tok " + t.hex()).strip() for t in texts))
+    out = _run_parser(micro_model, muts)
+    some = 0
+    for t in texts:
+        got = [int(x) for x in out[("tok " + t.hex()).strip()].split()]
+        assert got[0] == len(got) - 1
+        got = got[1:]
+        assert got == expected(t), (t, got, expected(t))
+        some += len(got) > 3
+    assert some > 30
