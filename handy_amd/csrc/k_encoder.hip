@@ -201,18 +201,277 @@ bool layer_norm_variant(int variant, const float *x, const float *w, const float
 
 // ------------------------------------------------------------------------------------------ attention
 // Non-causal softmax(Q K^T) V over T keys, heads of 64. Q is pre-scaled by 1/8 (kEncQScale, exact in fp16).
-// Workgroup = 4 waves = 128 query rows of one (utterance, head); each wave owns 32 rows and walks
-// the keys in tiles of 64 staged through LDS (LDS-DMA, double-buffered, XOR-swizzled).
 //   S^T = K Q^T      v_mfma_f32_32x32x16_f16, K rows as the A operand: a lane then holds scores of
-//                    ONE query (its column) for 16 keys per 32-key half, so the running max / sum
+//                    ONE query (its column) for 16 keys per 32-key half, so the reference exponent and the row sum
 //                    are per-lane scalars plus one exchange with the other lane half.
 //   O^T += V^T P^T   P^T is taken straight from the S^T accumulators (converted to fp16) as the B
 //                    operand; V arrives pre-transposed ([dh][enc_vt_pos(key)], written that way by the
 //                    QKV GEMM epilogues), read in the k-order the accumulator layout implies.
-// Bound: MFMA (4*T*T*64 flop per head). The output tile goes through LDS so rows are stored whole.
+// K and V^T tiles of 64 keys are staged through LDS by LDS-DMA (double-buffered, XOR-swizzled on the source side).
+// Nominally bound by the matrix pipe (4*T*T*64 flop per head); measured, it is bound by instruction issue: per score a lane
+// issues one fused multiply-add, one exponential (8 cycles), one add and half a conversion -- about 18 cycles -- and an MFMA
+// (32 cycles of the matrix pipe, 8 of issue) covers two scores per lane. The output tile goes through LDS so rows are stored whole.
 
 constexpr float kLog2e = 1.4426950408889634f;
 
+// Workgroup = 4 waves = 256 query rows of one (utterance, head); each wave owns 64 rows as two blocks of 32 (A and B). A K or
+// V^T fragment read from LDS feeds two MFMAs (one per block) and a staged tile serves 256 queries: half the LDS reads and
+// LDS-DMA instructions per score of a 32-queries-per-wave layout (enc_attention_kernel in the harness build, 9 % slower).
+// The keys are worked through in halves of a staged tile (32 keys): per half, Q K^T of block A, then Q K^T of B interleaved
+// with A's exponentials, then V^T P^T of A interleaved with B's exponentials, then V^T P^T of B -- independent work of the
+// other block under every MFMA group but the first and last, pinned with scheduling barriers.
+// The MFMAs accumulate raw scores (C = 0) and the reference exponent enters the exponential's argument through the fused
+// multiply-add that scales by log2(e): p = exp2(s * log2e - m * log2e), one rounding.
+// The reference m of a query is the maximum of its first 32 keys. Later halves exponentiate straight away and look at the sum
+// afterwards: while a lane's 16 values add up to less than kRedo = 2^15, each of them is below 2^15 -- fp16 holds that at full
+// relative precision (its maximum is 65504) and the sums are fp32, so the result is the same softmax, rounded alike. Only when
+// some query of the wave exceeds that does the wave read that block's scores again, move m up to the new maximum and rescale
+// what it has summed (wave-uniform branch, rare).
+__global__ __launch_bounds__(256, 2) void enc_attention_wide_kernel(const f16 *__restrict__ Q, const f16 *__restrict__ K, const f16 *__restrict__ Vt,
+                                                                    f16 *__restrict__ att, int H, int T, int Tp) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];    // per stage: K tile 8 KB + V^T tile 8 KB; the output tile at the end
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations need no VALU
+    // Workgroup ids are dealt round-robin to the 8 XCDs (one private L2 each): give every XCD a contiguous run of
+    // logical ids, so that the query blocks of one (utterance, head), which all stream the same K and V, share an L2.
+    const int nqb = (Tp + 255) / 256, nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int qblk = logical % nqb, bh_i = logical / nqb;
+    if (qblk * 256 >= T) return;                  // query rows that are all padding
+    const long bh = bh_i;
+    const int head = bh_i % H, b = bh_i / H;
+    const int q0 = qblk * 256 + wave * 64;
+    f16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const int qrow = min(q0 + qb * 32 + r, Tp - 1);          // rows past the padded length: any row, never stored
+        const f16 *qp = Q + (bh * Tp + qrow) * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) qf[qb][ks] = *(const f16x8 *)(qp + 16 * ks);
+    }
+    const f16 *kg = K + bh * Tp * 64;
+    const f16 *vg = Vt + bh * 64 * Tp;
+    // Staging by LDS-DMA, 16 bytes a lane: one wave-instruction moves a piece of 8 tile rows x 128 B to consecutive LDS
+    // addresses, so the XOR swizzle of the 16-byte slots is applied on the source side (lane (row, slot) fetches the slot
+    // that belongs there). A stage is 8 pieces of K rows and 8 of V^T rows; wave w moves pieces w and w + 4 of each.
+    // V^T needs no shuffling on the way: the P operand of the PV MFMA holds keys {16s + 4h + b, 16s + 8 + 4h + b} (b < 4) in
+    // one fragment, and enc_vt_pos() already put those two 4-key chunks side by side in global memory.
+    const int srow = lane >> 3, sslot = lane & 7;
+    int koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = (wave + 4 * i) * 8 + srow, src_slot = sslot ^ ((row >> 1) & 7);
+        koff[i] = row * 64 + src_slot * 8;
+        voff[i] = row * Tp + src_slot * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        char *base = smem + buf * 16384 + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + (long)kt * 4096 + koff[i]),
+                                             (__attribute__((address_space(3))) void *)(base + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + (long)kt * 64 + voff[i]),
+                                             (__attribute__((address_space(3))) void *)(base + 8192 + i * 4096), 16, 0, 0);
+        }
+    };
+    // every piece of a stage has landed (each wave waits for its own, the barrier joins them) and every wave is done reading
+    // the other stage
+    auto stage_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // byte offset of this lane's fragment j (16-byte chunk 2 j + h, swizzled) inside its tile row: K fragments ks = j of key row
+    // kh * 32 + r, V^T fragments of key chunk 2 j + h = 4 kh + 2 sidx + h of row blk * 32 + r
+    int foff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) foff[j] = r * 128 + (((2 * j + h) ^ ((r >> 1) & 7)) << 4);
+
+    f32x16 o[2][2], zero;                        // o[query block][dh block]
+#pragma unroll
+    for (int i = 0; i < 16; i++) { o[0][0][i] = 0.0f; o[0][1][i] = 0.0f; o[1][0][i] = 0.0f; o[1][1][i] = 0.0f; zero[i] = 0.0f; }
+    float m_run[2] = {0.0f, 0.0f}, nm[2] = {0.0f, 0.0f}, l_run[2] = {0.0f, 0.0f};      // nm = -m_run * log2(e)
+    const int n_tiles = (T + 63) / 64, n_half = (T + 31) / 32;
+    const bool ragged = (T & 31) != 0;
+    constexpr float kRedo = 32768.0f;
+
+    // One half of a staged tile: keys kt * 64 + KH * 32 .. + 31. FIRST: the very first half (sets the references); MASK: it
+    // holds keys past T.
+    auto half = [&](int kt, const char *kb, const char *vb, auto kh_tag, auto first_tag, auto mask_tag) __attribute__((always_inline)) {
+        constexpr int KH = decltype(kh_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value, MASK = decltype(mask_tag)::value;
+        f16x8 kf[4], vf[2][2];
+        f32x16 sa, sb;
+        f16x8 pa[2], pb[2];
+        float lsum_a = 0.0f, lsum_b = 0.0f;
+        auto read_k = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) kf[ks] = *(const f16x8 *)(kb + KH * 4096 + foff[ks]);
+        };
+        auto read_v = [&]() {
+#pragma unroll
+            for (int sidx = 0; sidx < 2; sidx++)
+#pragma unroll
+                for (int blk = 0; blk < 2; blk++) vf[sidx][blk] = *(const f16x8 *)(vb + blk * 4096 + foff[KH * 2 + sidx]);
+        };
+        auto mask = [&](f32x16 &s) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int key = kt * 64 + KH * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (key >= T) s[i] = -INFINITY;
+            }
+        };
+        auto qk = [&](f32x16 &s, int qb) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[qb][ks], ks == 0 ? zero : s, 0, 0, 0);
+            if (MASK) mask(s);
+        };
+        auto exps = [&](const f32x16 &s, float nmq, float &lsum, f16x8 (&pf)[2], auto i0_tag, auto n_tag) {
+            constexpr int i0 = decltype(i0_tag)::value, n = decltype(n_tag)::value;
+#pragma unroll
+            for (int e = 0; e < n; e++) {
+                const int i = i0 + e;
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], kLog2e, nmq));
+                lsum += p;
+                pf[i >> 3][i & 7] = (f16)p;
+            }
+        };
+        auto exps_all = [&](const f32x16 &s, float nmq, float &lsum, f16x8 (&pf)[2]) {
+            lsum = 0.0f;
+            exps(s, nmq, lsum, pf, std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
+        };
+        // the reference of block qb moves up to the maximum of s (first: is set to it); what has been summed is rescaled
+        auto move_reference = [&](const f32x16 &s, int qb, bool first) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = first ? mx : fmaxf(mx, m_run[qb]);
+            if (!first) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; i++) { o[qb][0][i] *= alpha; o[qb][1][i] *= alpha; }
+            }
+            m_run[qb] = m_new;
+            nm[qb] = -m_new * kLog2e;
+        };
+        auto redo = [&](f32x16 &s, int qb, float &lsum, f16x8 (&pf)[2]) {       // wave-uniform, rare
+            asm volatile("" ::: "memory");
+            read_k();
+            qk(s, qb);
+            move_reference(s, qb, false);
+            exps_all(s, nm[qb], lsum, pf);
+        };
+        auto pv = [&](int qb, const f16x8 (&pf)[2], auto g_tag) {
+            constexpr int g = decltype(g_tag)::value, sidx = g >> 1, blk = g & 1;
+            o[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[sidx][blk], pf[sidx], o[qb][blk], 0, 0, 0);
+        };
+
+        read_k();
+        read_v();
+        qk(sa, 0);
+        if constexpr (FIRST) {
+            qk(sb, 1);
+            move_reference(sa, 0, true);
+            move_reference(sb, 1, true);
+            exps_all(sa, nm[0], lsum_a, pa);
+        } else {
+            // Q K^T of block B, one MFMA per gap, under block A's exponentials (letting the first of these MFMAs go ahead of
+            // the exponentials, so that the wave has something to issue while block A's last MFMA finishes, was 1.5 % slower)
+            __builtin_amdgcn_sched_barrier(0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[1][0], zero, 0, 0, 0);
+            exps(sa, nm[0], lsum_a, pa, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[1][1], sb, 0, 0, 0);
+            exps(sa, nm[0], lsum_a, pa, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2], qf[1][2], sb, 0, 0, 0);
+            exps(sa, nm[0], lsum_a, pa, std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[3], qf[1][3], sb, 0, 0, 0);
+            exps(sa, nm[0], lsum_a, pa, std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (MASK) mask(sb);
+            asm volatile("" : "+v"(lsum_a), "+v"(pa[0]), "+v"(pa[1]));
+            if (__builtin_amdgcn_ballot_w64(lsum_a >= kRedo) != 0) redo(sa, 0, lsum_a, pa);
+        }
+        l_run[0] += lsum_a;
+        // V^T P^T of block A under block B's exponentials
+        __builtin_amdgcn_sched_barrier(0);
+        pv(0, pa, std::integral_constant<int, 0>{});
+        exps(sb, nm[1], lsum_b, pb, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+        pv(0, pa, std::integral_constant<int, 1>{});
+        exps(sb, nm[1], lsum_b, pb, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+        pv(0, pa, std::integral_constant<int, 2>{});
+        exps(sb, nm[1], lsum_b, pb, std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+        pv(0, pa, std::integral_constant<int, 3>{});
+        exps(sb, nm[1], lsum_b, pb, std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!FIRST) {
+            asm volatile("" : "+v"(lsum_b), "+v"(pb[0]), "+v"(pb[1]));
+            if (__builtin_amdgcn_ballot_w64(lsum_b >= kRedo) != 0) redo(sb, 1, lsum_b, pb);
+        }
+        l_run[1] += lsum_b;
+        pv(1, pb, std::integral_constant<int, 0>{}); pv(1, pb, std::integral_constant<int, 1>{});
+        pv(1, pb, std::integral_constant<int, 2>{}); pv(1, pb, std::integral_constant<int, 3>{});
+    };
+    using No = std::false_type; using Yes = std::true_type;
+    using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>;
+    auto tile = [&](int kt, auto first_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const char *kb = smem + (kt & 1) * 16384, *vb = kb + 8192;
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+        if constexpr (!LAST) {
+            half(kt, kb, vb, H0{}, first_tag, No{});
+            half(kt, kb, vb, H1{}, No{}, No{});
+        } else if (n_half & 1) {                 // the tile's second half is all padding
+            if (ragged) half(kt, kb, vb, H0{}, first_tag, Yes{}); else half(kt, kb, vb, H0{}, first_tag, No{});
+        } else {
+            half(kt, kb, vb, H0{}, first_tag, No{});
+            if (ragged) half(kt, kb, vb, H1{}, No{}, Yes{}); else half(kt, kb, vb, H1{}, No{}, No{});
+        }
+        stage_barrier();
+    };
+    stage(0, 0);
+    stage_barrier();
+    if (n_tiles == 1) tile(0, Yes{}, Yes{});
+    else {
+        tile(0, Yes{}, No{});
+        for (int kt = 1; kt + 1 < n_tiles; kt++) tile(kt, No{}, No{});
+        tile(n_tiles - 1, No{}, Yes{});
+    }
+    // normalise, stage the [256 q][64 dh] tile in LDS, store whole rows
+    char *ob = smem;
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+        const float inv = 1.0f / l_tot;
+        const int orow = wave * 64 + qb * 32 + r;
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x16 &ov = o[qb][blk];
+                const f16x4 v4 = {(f16)(ov[4 * g] * inv), (f16)(ov[4 * g + 1] * inv), (f16)(ov[4 * g + 2] * inv), (f16)(ov[4 * g + 3] * inv)};
+                *(f16x4 *)(ob + orow * 128 + (((4 * blk + g) ^ (orow & 7)) << 4) + 8 * h) = v4;
+            }
+    }
+    __syncthreads();
+    const int d = H * 64;
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int idx = p * 256 + tid, row = idx >> 3, ch = idx & 7, q = qblk * 256 + row;
+        if (q < T) *(f16x8 *)(att + ((long)b * T + q) * d + head * 64 + ch * 8) = *(const f16x8 *)(ob + row * 128 + ((ch ^ (row & 7)) << 4));
+    }
+}
+
+#ifdef WMI_HARNESS
+// The 32-queries-per-wave layout the product kernel replaced (128 queries per workgroup, three waves per SIMD, whole 64-key
+// tiles, the reference exponent as the C operand of a tile's first MFMA): kept for A/B runs (scripts/enc_attention_ab.py).
 __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restrict__ Q, const f16 *__restrict__ K, const f16 *__restrict__ Vt,
                                                             f16 *__restrict__ att, int H, int T, int Tp) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];    // per stage: K tile 8 KB + V^T tile 8 KB
@@ -400,16 +659,16 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16 *__restric
 }
 
 
-#ifdef WMI_HARNESS
-// The same attention, software-pipelined inside each wave. Iteration t of a wave works on three key tiles at once: the matrix
+
+// enc_attention_kernel (above), software-pipelined inside each wave. Iteration t of a wave works on three key tiles at once: the matrix
 // pipe multiplies Q K^T of tile t + 1 and V^T P^T of tile t - 1 (16 MFMAs, none of which depends on anything this iteration
 // computes) while the vector pipe exponentiates tile t's scores (32 per lane: multiply, exponential, add, convert), the two
 // streams interleaved by hand -- one MFMA, then two scores' worth of vector work, pinned with scheduling barriers -- so that
-// the matrix pipe's 32 cycles per MFMA run under the vector instructions instead of beside another wave's. In the kernel above
-// that overlap depends on another wave of the SIMD being in the other phase, and the per-tile barrier keeps a workgroup's
+// the matrix pipe's 32 cycles per MFMA run under the vector instructions instead of beside another wave's. In that kernel
+// the overlap depends on another wave of the SIMD being in the other phase, and the per-tile barrier keeps a workgroup's
 // waves in step. Costs a second set of score and probability registers (two waves per SIMD instead of three) and a third K
 // stage in LDS; V^T stays double-buffered (V^T of tile t is requested in iteration t and multiplied in t + 1).
-// The arithmetic is the kernel's above, operation for operation: same accumulation chains, same order of the partial sums,
+// The arithmetic is that kernel's, operation for operation: same accumulation chains, same order of the partial sums,
 // and a tile that moves the reference m_run (rare) recomputes its own scores and those of the tile after it from the K tiles
 // still in the ring, with the new -m_run as the accumulators' starting value. The outputs are bit-identical.
 // ABL (harness only, wrong results): 1 no exponential, 2 no MFMA in the gaps, 3 no workgroup barrier, 4 no LDS fragment reads,
@@ -715,8 +974,8 @@ bool lds_pattern_bench(int pattern, int do_read, int iters, float *ms_out) {
 #endif  // WMI_HARNESS
 
 #ifdef WMI_HARNESS
-// which attention kernel enc_attention() launches in the harness library: 0 enc_attention_kernel, 1 enc_attention_pipe_kernel,
-// 11..17 its ablations (WMI_ENC_ATTN at load, wmi_debug_set_enc_attention afterwards)
+// which attention kernel enc_attention() launches in the harness library: 0 the product's (enc_attention_wide_kernel),
+// 3 enc_attention_kernel, 1 enc_attention_pipe_kernel, 11..17 its ablations (WMI_ENC_ATTN at load, wmi_debug_set_enc_attention afterwards)
 std::atomic<int> g_enc_attention_variant{[] { const char *e = getenv("WMI_ENC_ATTN"); return e ? atoi(e) : 0; }()};
 void enc_attention_set_variant(int v) { g_enc_attention_variant.store(v, std::memory_order_relaxed); }
 #endif
@@ -724,16 +983,17 @@ void enc_attention_set_variant(int v) { g_enc_attention_variant.store(v, std::me
 bool enc_attention(const f16 *Q, const f16 *K, const f16 *Vt, f16 *att, int B, int H, int T, int Tp, hipStream_t st) {
     if (B <= 0) return true;
     if (Tp % 128 != 0 || T > Tp) { log_msg(2, "enc_attention: bad padding T=%d Tp=%d\n", T, Tp); return false; }
-    const dim3 grid((Tp / 128) * H * B);
 #ifdef WMI_HARNESS
+    const dim3 grid((Tp / 128) * H * B);
     switch (g_enc_attention_variant.load(std::memory_order_relaxed)) {
+        case 3: hipLaunchKernelGGL(enc_attention_kernel, grid, dim3(256), 0, st, Q, K, Vt, att, H, T, Tp); return hipGetLastError() == hipSuccess;
 #define WMI_PIPE(V_, A_) case V_: hipLaunchKernelGGL(enc_attention_pipe_kernel<A_>, grid, dim3(256), 0, st, Q, K, Vt, att, H, T, Tp); return hipGetLastError() == hipSuccess;
         WMI_PIPE(1, 0) WMI_PIPE(11, 1) WMI_PIPE(12, 2) WMI_PIPE(13, 3) WMI_PIPE(14, 4) WMI_PIPE(15, 5) WMI_PIPE(16, 6) WMI_PIPE(17, 7)
 #undef WMI_PIPE
         default: break;
     }
 #endif
-    hipLaunchKernelGGL(enc_attention_kernel, grid, dim3(256), 0, st, Q, K, Vt, att, H, T, Tp);
+    hipLaunchKernelGGL(enc_attention_wide_kernel, dim3(((Tp + 255) / 256) * H * B), dim3(256), 0, st, Q, K, Vt, att, H, T, Tp);
     return hipGetLastError() == hipSuccess;
 }
 

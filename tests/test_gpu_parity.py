@@ -70,14 +70,17 @@ def test_gelu_epilogue_over_every_f16_input(wr, M):
     assert not out[:, n_per:64].any() and not out[:, 64:].any()              # gelu(0) = 0 everywhere else
 
 
-@pytest.mark.parametrize("T", [1500, 100, 40, 64, 192])
+@pytest.mark.parametrize("T", [1500, 100, 40, 64, 192, 33, 97, 257, 300])
 @pytest.mark.parametrize("shape", ["random", "rising", "spike", "falling", "low_start"])
 def test_encoder_attention_kernel_against_float64_softmax(wr, T, shape):
-    """enc_attention_kernel on score profiles that move its reference exponent: the kernel takes tile 0's maximum as the
-    reference and moves it only when a later 64-key tile exceeds it by a margin, so bounded random data never leaves the
-    fast path. `rising` climbs 30 - 90 units over the keys (many moves), `spike` puts one key 16 - 48 units above the rest late in
-    the sequence, `falling` makes everything after tile 0 underflow, `low_start` starts 24 - 72 units below the rest. Reference:
-    softmax in float64 on the fp16 inputs; the kernel rounds p to fp16 before the PV product: 2^-11 relative."""
+    """The encoder's attention kernel on score profiles that move its reference exponent: the kernel takes the maximum of a
+    query's first 32 keys as the reference and moves it only when a later half-tile of 32 keys exceeds it by a margin, so
+    bounded random data never leaves the fast path. `rising` climbs 30 - 90 units over the keys (many moves), `spike` puts one key
+    16 - 48 units above the rest late in the sequence, `falling` makes everything after the first tile underflow, `low_start`
+    starts 24 - 72 units below the rest. Lengths: the encoder's own 1500; a ragged last half-tile (100, 40, 33, 97, 300), whole
+    tiles (64, 192), a padded second half of the last tile (33, 97, 257), more than one 256-query workgroup per head with query
+    rows past the padded length (257, 300). Reference: softmax in float64 on the fp16 inputs; the kernel rounds p to fp16
+    before the PV product: 2^-11 relative."""
     import ctypes as C
     L = wr.load_library()
     L.wmi_debug_enc_attention.restype = C.c_int
