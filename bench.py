@@ -54,7 +54,7 @@ CONFIGS = {
 }
 CLASS_KERNEL = {
     "enc_gemm": ("mfma", "gemm_nt8p_kernel / gemm_nt8_kernel / gemm_nt_kernel (encoder conv, QKV, out, MLP, cross-K/V GEMMs)"),
-    "enc_attn": ("mfma", "enc_attention_kernel"),
+    "enc_attn": ("mfma", "enc_attention_wide_kernel"),
     "dec_cross_attn": ("hbm", "dec_cross_attention_kernel / dec_cross_attention_mq_kernel (cached encoder K/V streamed once per utterance and layer)"),
     "dec_gemm": ("hbm", "gemm_skinny_kernel / gemm_nt_kernel on decoder rows (decoder weights streamed once per pass)"),
     "mel": ("hbm", "mel_raw_kernel + mel_normalize_batch_kernel (PCM in; clamped, scaled fp32 log-mel out)"),

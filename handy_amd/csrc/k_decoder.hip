@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(float *__restrict__
         float v = -INFINITY;
         if (i < V) {
             v = lg[i];
+            const float v_in = v;
             if (sr.temperature > 0.0f && !stage_b) v = v / sr.temperature;
             if (!raw) {
                 bool kill = false;
@@ -421,7 +422,9 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(float *__restrict__
                     if (has_ts && i >= vi.beg && i < vi.beg + sr.ts_min) kill = true;
                 }
                 if (kill) v = -INFINITY;
-                lg[i] = v;
+                // only what a rule changed goes back (a greedy step changes a few hundred of a row's 52 k values: the row is
+                // then read once instead of read and rewritten)
+                if (__float_as_uint(v) != __float_as_uint(v_in)) lg[i] = v;
             }
             if (i < vi.beg) { if (v > mt.v) { mt.v = v; mt.i = i; } }
             else if (v > ms.v) { ms.v = v; ms.i = i; }

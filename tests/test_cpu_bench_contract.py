@@ -1,4 +1,4 @@
-"""The benchmark's output contract, checked on the committed lines of this round (profiles/r02_*.json[l]): every line bench.py
+"""The benchmark's output contract, checked on the committed lines of this round (profiles/r03_*.json[l]): every line bench.py
 printed on the GPU box carries the fields the driver and the judge read, with consistent values."""
 import json
 import os
@@ -12,7 +12,7 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def _lines():
     out = []
-    for name in ("r02_bench_b1024.json", "r02_configs.jsonl"):
+    for name in ("r03_bench_b1024.json", "r03_configs.jsonl"):
         with open(os.path.join(ROOT, "profiles", name)) as f:
             out += [(name, json.loads(l)) for l in f if l.strip()]
     return out
@@ -41,7 +41,7 @@ def test_committed_bench_lines_follow_the_contract(name, line):
 
 
 def test_headline_line_is_the_baseline_workload_with_its_extra_legs():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_b1024.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_b1024.json")))
     assert "large-v3-turbo" in line["metric"] and line["config"]["utterances_per_gpu"] == 1024 and line["config"]["tokens_per_utterance"] == 128
     assert line["roofline"]["bound"] == "mfma" and line["roofline"]["traffic"] > 0
     s = line["strong_scaling"]
