@@ -380,7 +380,8 @@ __global__ __launch_bounds__(256, 2) void enc_attention_wide_kernel(const f16 *_
             // Q K^T of block B, one MFMA per gap, under block A's exponentials (letting the first of these MFMAs go ahead of
             // the exponentials, so that the wave has something to issue while block A's last MFMA finishes, was 1.5 % slower;
             // reading the next half's K fragments one half ahead, under V^T P^T of block B, changed nothing: with two waves on
-            // a SIMD neither wait is what the SIMD's issue slots are lost to)
+            // a SIMD neither wait is what the SIMD's issue slots are lost to; eight waves and 512 queries per workgroup, which
+            // halves the LDS-DMA instructions per query once more, was 3.6 % slower: one workgroup per CU, its waves in step)
             __builtin_amdgcn_sched_barrier(0);
             sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[1][0], zero, 0, 0, 0);
             exps(sa, nm[0], lsum_a, pa, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
