@@ -205,6 +205,8 @@ wmi_node *wmi_node_init(const char *path_model, const int *devices, int n_device
         int ndev = 0;
         if (!path_model || batch < 1 || n_devices < 0 || n_devices > 64) return nullptr;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { log_msg(2, "wmi_node_init: no HIP device\n"); return nullptr; }
+        int dev_before = 0;            // the calling thread's current device is put back before returning
+        (void)hipGetDevice(&dev_before);
         wmi_node *node = new wmi_node();
         node->batch = batch;
         if (n_devices == 0 || !devices) for (int d = 0; d < ndev; d++) node->devices.push_back(d);     // every visible GPU
@@ -215,12 +217,19 @@ wmi_node *wmi_node_init(const char *path_model, const int *devices, int n_device
         // the engines load side by side: each thread reads the file and uploads to its own GPU
         std::vector<std::thread> th;
         auto load = [&](int w) {
-            node->ctx[w] = wmi_ctx_for_device(path_model, node->devices[w]);
-            if (node->ctx[w]) node->state[w] = wmi_init_state_batch(node->ctx[w], batch, max_decoders, enc_chunk);
+            try {
+                node->ctx[w] = wmi_ctx_for_device(path_model, node->devices[w]);
+                if (node->ctx[w]) node->state[w] = wmi_init_state_batch(node->ctx[w], batch, max_decoders, enc_chunk);
+            } catch (...) {}           // the engine stays unset: reported below
         };
-        for (int w = 1; w < n; w++) th.emplace_back(load, w);
+        int started = 1;
+        try {
+            for (; started < n; started++) th.emplace_back(load, started);
+        } catch (...) {}               // no more threads to be had: the remaining engines load on this one
         load(0);
         for (auto &t : th) t.join();
+        for (int w = started; w < n; w++) load(w);
+        (void)hipSetDevice(dev_before);
         for (int w = 0; w < n; w++)
             if (!node->state[w]) { log_msg(2, "wmi_node_init: engine %d (device %d) failed to start\n", w, node->devices[w]); wmi_node_free(node); return nullptr; }
         return node;
@@ -229,11 +238,14 @@ wmi_node *wmi_node_init(const char *path_model, const int *devices, int n_device
 
 void wmi_node_free(wmi_node *node) {
     if (!node) return;
+    int dev_before = 0;
+    const bool have_dev = hipGetDevice(&dev_before) == hipSuccess;
     for (size_t w = 0; w < node->ctx.size(); w++) {
         (void)hipSetDevice(node->devices[w]);
         whisper_free_state(node->state[w]);
         whisper_free(node->ctx[w]);
     }
+    if (have_dev) (void)hipSetDevice(dev_before);
     delete node;
 }
 
@@ -254,6 +266,8 @@ int wmi_node_run(wmi_node *node, struct whisper_full_params params, const float 
         EngineJob job{node, &params, samples, n_samples};
         node->last_batches.assign(n, 0);
         node->last_gather = 0;
+        // worker 0 is the calling thread: its current device is put back when the job is over
+        struct DeviceGuard { int d = 0; bool ok; DeviceGuard() : ok(hipGetDevice(&d) == hipSuccess) {} ~DeviceGuard() { if (ok) (void)hipSetDevice(d); } } guard;
         const int rc = run_queue(n, n_utts, node->batch, engine_batch, &job, records_out, node->last_batches.data());
         if (rc != 0) return rc;
         // the gather: with more than one distinct GPU the records of device w travel to device 0 over RCCL (xGMI); they are
