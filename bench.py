@@ -384,7 +384,9 @@ def main():
             assert allrec is not None and allrec[:, 0].tolist() == list(range(args.strong_total)), "strong-scaling job: records missing or duplicated"
             assert int((allrec[:, 1] == tokens + 1).all()), "strong-scaling job: wrong token count"
             strong = {"utterances": args.strong_total, "batch": sb, "batches": n_batches, "batches_pulled_by_rank0": pulled, "batches_taken_from_log": len(already), "result_log": log_dir, "seconds": sdt,
-                      "value": 30.0 * args.strong_total / sdt, "unit": "audio-sec/sec", "scaling": "strong",
+                      # a resumed job is priced on what this run transcribed (None when the log already held everything)
+                      "value": (30.0 * sum(min((b + 1) * sb, args.strong_total) - b * sb for b in range(n_batches) if b not in already) / sdt) if len(already) < n_batches else None,
+                      "unit": "audio-sec/sec", "scaling": "strong",
                       "note": "ranks pull batches from a shared queue (atomic counter on the rendezvous store), token records gathered once at the end"}
             log(f"strong-scaling job: {sdt:.2f} s")
 
