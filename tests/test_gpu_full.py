@@ -323,6 +323,52 @@ def test_full_params_variants_match_oracle(wr, oracle, model_path, variant):
     del keep
 
 
+def test_initial_prompt_text_goes_through_the_tokenizer(wr, model_path):
+    """`initial_prompt` (text) and `prompt_tokens` (ids) are the same request once the text is tokenised: whisper_tokenize through
+    the C ABI gives the ids of the word-pattern / longest-entry rule (restated with Python's `re`; the rule itself is held to
+    that restatement on many texts, under the sanitizers, in tests/test_cpu_sanitizers.py), and a transcription prompted with
+    the text equals one prompted with those ids and differs from an unprompted one."""
+    import re
+    from handy_amd import ggml_file
+    path = model_path("micro", decisive=4.0)
+    vocab = ggml_file.read_model(path).vocab
+    ids = {t: i for i, t in enumerate(vocab)}
+    pat = re.compile(rb"'s|'t|'re|'ve|'m|'ll|'d| ?[A-Za-z]+| ?[0-9]+| ?[^\sA-Za-z0-9]+|\s+(?!\S)|\s+")
+    words = [t.decode() for t in vocab[300:330]]
+    text = "".join(w if w.startswith(" ") else " " + w for w in words[:12]) + "'s 42, ok?  "
+    want = []
+    for w in pat.findall(text.encode()):
+        i = 0
+        while i < len(w):
+            for j in range(len(w), i, -1):
+                if w[i:j] in ids:
+                    want.append(ids[w[i:j]]); i = j
+                    break
+            else:
+                i += 1
+    ctx = wr.WhisperContext(path)
+    got = ctx.tokenize(text)
+    assert got == want and len(got) >= 12, (got, want)
+    pcm = synth_pcm(77, 16000 * 20)
+
+    def run(setup):
+        st = ctx.create_batch_state(1, 1, 1)
+        fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language("en")
+        keep = setup(fp)
+        st.full_batch(fp, [pcm])
+        out = [(g.tokens, g.t0, g.t1) for g in st.batch_segments(0)]
+        st.free()
+        del keep
+        return out
+
+    by_text = run(lambda fp: fp.set_initial_prompt(text))
+    by_ids = run(lambda fp: fp.set_tokens(got))
+    plain = run(lambda fp: None)
+    ctx.free()
+    assert by_text == by_ids and sum(len(t) for t, _, _ in by_text) > 5
+    assert by_text != plain
+
+
 def test_batching_front_equals_one_call_at_a_time(wr, oracle, model_path):
     """handy_amd.manager.TranscriptionManager: concurrent transcribe() calls are served by shared GPU batches and
     every caller still gets exactly what a lone call returns (beam search, transcribe-rs defaults) -- which is the text the
