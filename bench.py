@@ -15,6 +15,8 @@ position).
   headline        large-v3-turbo, greedy, 128 tokens                    (the 10k x 30 s job run as batches; weak scaling)
   small32         Whisper small, 32 x 30 s, greedy, 128 tokens
   largev3_beam5   Whisper large-v3, 64 x 30 s, beam size 5, 64 tokens
+  turbo_beam3     large-v3-turbo, 256 x 30 s, beam size 3, 64 tokens     (the headline model under the beam width Handy's
+                  transcribe-rs engine defaults to; not a BASELINE workload)
   tiny1           Whisper tiny.en, one 30 s clip, greedy, 64 tokens      (latency of the call Handy makes)
   mel80 / mel128  log-mel frontend only, 1 h of audio (120 x 30 s)
 
@@ -48,6 +50,7 @@ CONFIGS = {
     "headline":      ("large-v3-turbo", 1024,      128,   1,    "enc_gemm"),
     "small32":       ("small",          32,        128,   1,    "dec_gemm"),
     "largev3_beam5": ("large-v3",       64,        64,    5,    "dec_cross_attn"),
+    "turbo_beam3":   ("large-v3-turbo", 256,       64,    3,    "enc_gemm"),
     "tiny1":         ("tiny.en",        1,         64,    1,    "dec_gemm"),
     "mel80":         ("micro.en",       120,       0,     1,    "mel"),
     "mel128":        ("micro-v3",       120,       0,     1,    "mel"),
