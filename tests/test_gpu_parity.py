@@ -19,7 +19,9 @@ def _f16(x):
     return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 192, 256), (64, 64, 64), (1, 128, 128), (300, 256, 1280), (5, 51968 // 4, 128), (3000, 2048, 256), (2047, 1280, 1280)])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 256), (64, 64, 64), (1, 128, 128), (300, 256, 1280), (5, 51968 // 4, 128), (3000, 2048, 256), (2047, 1280, 1280),
+                                   # two or more 256 x 256 tiles per CU: the persistent kernel (whole and ragged last row tile, fp32 rows out)
+                                   (33024, 1280, 256), (26500, 1536, 384)])
 def test_gemm_matches_numpy(wr, M, N, K):
     rng = np.random.default_rng(M * 7 + N)
     A = rng.standard_normal((M, K), dtype=np.float32)
@@ -32,9 +34,10 @@ def test_gemm_matches_numpy(wr, M, N, K):
     assert err <= 2e-3 * max(1.0, np.abs(ref).max()), err
 
 
-@pytest.mark.parametrize("M", [1024, 24576])
+@pytest.mark.parametrize("M", [1024, 24576, 132096])
 def test_gelu_epilogue_over_every_f16_input(wr, M):
-    """The GELU fused into the fc1 GEMM (both tile paths: 64x64 for 1024 rows, 256x256 with the staged epilogue for 24576) on every finite fp16 value,
+    """The GELU fused into the fc1 GEMM (every tile path: 64x64 for 1024 rows, 256x256 with the staged epilogue for 24576, the
+    persistent 256x256 kernel -- 516 tiles, K = 128 -- for 132096) on every finite fp16 value,
     against ggml's definition -- the tanh form evaluated on the fp16 input and rounded to fp16 (the values of its lookup
     table), 0 at and below -10, the input itself at and above 10. The kernel's exp and reciprocal are hardware
     approximations: at most one fp16 ulp off (5e-7 absolute in the cancelling negative tail), on a small share of inputs."""
@@ -43,7 +46,7 @@ def test_gelu_epilogue_over_every_f16_input(wr, M):
     bits = np.arange(65536, dtype=np.uint16)
     h = bits.view(np.float16)
     vals = np.where(np.isfinite(h), h, np.float16(0)).astype(np.float32)
-    K = 64
+    K = 128 if M > 100000 else 64
     A = np.zeros((M, K), np.float32)
     n_per = 65536 // 1024
     A[:1024, :n_per] = vals.reshape(1024, n_per)                           # value j of row i sits in column j
