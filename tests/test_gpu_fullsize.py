@@ -218,6 +218,29 @@ def test_headline_shape_1024_utterances(wr, turbo_path):
     st1.free(); ctx.free()
 
 
+def test_encoder_result_does_not_depend_on_its_chunk(wr, turbo_path):
+    """An utterance's encoder numbers do not depend on what shares its encoder chunk: the cross-attention K/V of a clip encoded
+    inside a chunk of 128 utterances -- every GEMM then runs the persistent 256 x 256 kernel (bias / GELU / residual / head
+    scatter / transposed-V epilogues) -- equal, bit for bit and in every decoder layer, those of the same clip encoded alone
+    (256 x 128 and 64 x 64 tiles: every tile shape adds K in the same order; attention and LayerNorm are per row)."""
+    ctx = wr.WhisperContext(turbo_path)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1))
+    fp.set_temperature_inc(0.0); fp.set_no_timestamps(True); fp.set_language("en")
+    clips = [synth_pcm(900 + i, int(16000 * s)) for i, s in enumerate((30.0, 30.0, 11.0, 30.0, 24.5, 30.0, 30.0, 2.0))]
+    B = 256
+    st = ctx.create_batch_state(B, 1, 128); st.set_force_tokens(2)
+    st.full_batch(fp, [clips[i % 8] for i in range(B)])
+    big = [st.cross_kv(l) for l in range(ctx.n_text_layer())]          # utterance slot 0 = clip 0
+    st.free()
+    st1 = ctx.create_batch_state(1, 1, 1); st1.set_force_tokens(2)
+    st1.full_batch(fp, [clips[0]])
+    one = [st1.cross_kv(l) for l in range(ctx.n_text_layer())]
+    st1.free(); ctx.free()
+    for l, ((kb, vb), (k1, v1)) in enumerate(zip(big, one)):
+        assert np.abs(k1).max() > 1.0 and np.isfinite(k1).all()
+        assert np.array_equal(kb, k1) and np.array_equal(vb, v1), (l, int((kb != k1).sum()), int((vb != v1).sum()))
+
+
 def test_largev3_beam5_shape_64_utterances(wr, oracle, v3_path):
     from test_gpu_full import _oracle_params, _same
     ctx = wr.WhisperContext(v3_path)
