@@ -370,6 +370,82 @@ def test_initial_prompt_text_goes_through_the_tokenizer(wr, model_path):
     assert by_text != plain
 
 
+def test_low_level_entry_points(wr, model_path):
+    """The rest of the whisper.h surface whisper-rs binds, each through the C ABI: a context from a memory buffer transcribes as
+    the one from the file does; a log-mel handed in with whisper_set_mel_with_state encodes to the same bits as the one the
+    engine computed itself (and whisper_n_len_from_state counts its frames); whisper_full_default_params_by_ref returns what
+    the by-value call returns; whisper_print_system_info names the device path; whisper_print_timings / whisper_reset_timings
+    go through the log callback; speaker_turn_next reads false without tinydiarize tokens."""
+    path = model_path("micro", decisive=4.0)
+    L = wr.load_library()
+    pcm = synth_pcm(21, 16000 * 12)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language("en")
+
+    def transcript(ctx):
+        st = ctx.create_batch_state(1, 1, 1)
+        st.full_batch(fp, [pcm])
+        out = [(g.tokens, g.t0, g.t1) for g in st.batch_segments(0)]
+        st.free()
+        return out
+
+    ctx = wr.WhisperContext(path)
+    ctx_b = wr.WhisperContext.from_buffer(open(path, "rb").read())
+    a, b = transcript(ctx), transcript(ctx_b)
+    assert a == b and sum(len(t) for t, _, _ in a) > 3
+    ctx_b.free()
+    with pytest.raises(wr.WhisperError):
+        wr.WhisperContext.from_buffer(open(path, "rb").read()[:5000])            # a truncated image is refused, not read past
+
+    s1 = ctx.create_state(); s2 = ctx.create_state()
+    s1.pcm_to_mel(pcm)
+    n = s1.n_len()
+    assert n == 1 + (pcm.size + 200 - 400) // 160                                 # whisper.cpp reports the frames of the audio itself (mel.n_len_org)
+    mel = s1.get_mel(3000)
+    s1.encode(0)
+    e1 = s1.encoder_output()
+    s2.set_mel(mel)
+    assert s2.n_len() == 3000
+    s2.encode(0)
+    e2 = s2.encoder_output()
+    assert np.array_equal(e1, e2) and np.abs(e1).max() > 0.5
+    with pytest.raises(wr.WhisperError):
+        s2.set_mel(np.zeros((ctx.n_mels() + 1, 100), np.float32))                 # wrong number of mel bands
+    # speaker turns: no tinydiarize token in this vocabulary's output
+    s1.full(fp, pcm)
+    assert s1.full_n_segments() >= 1
+    L.whisper_full_get_segment_speaker_turn_next_from_state.argtypes = [C.c_void_p, C.c_int]
+    L.whisper_full_get_segment_speaker_turn_next_from_state.restype = C.c_bool
+    assert not any(L.whisper_full_get_segment_speaker_turn_next_from_state(s1.h, i) for i in range(s1.full_n_segments()))
+    s1.free(); s2.free()
+
+    L.whisper_full_default_params_by_ref.restype = C.POINTER(wr.whisper_full_params)
+    L.whisper_full_default_params_by_ref.argtypes = [C.c_int]
+    for strategy in (0, 1):
+        pr = L.whisper_full_default_params_by_ref(strategy)
+        by_val = L.whisper_full_default_params(strategy)
+        assert pr and bytes(C.string_at(C.addressof(pr.contents), C.sizeof(wr.whisper_full_params))) == \
+            bytes(C.string_at(C.addressof(by_val), C.sizeof(wr.whisper_full_params)))
+        L.whisper_free_params.argtypes = [C.c_void_p]; L.whisper_free_params.restype = None
+        L.whisper_free_params(C.cast(pr, C.c_void_p))
+    info = L.whisper_print_system_info()
+    assert info and (b"HIP" in info or b"gfx" in info or b"MI3" in info), info
+
+    lines = []
+    cb_t = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
+    cb = cb_t(lambda level, text, user: lines.append(text.decode(errors="replace")))
+    L.whisper_log_set.argtypes = [cb_t, C.c_void_p]; L.whisper_log_set.restype = None
+    L.whisper_log_set(cb, None)
+    try:
+        L.whisper_print_timings.argtypes = [C.c_void_p]; L.whisper_print_timings.restype = None
+        L.whisper_reset_timings.argtypes = [C.c_void_p]; L.whisper_reset_timings.restype = None
+        L.whisper_print_timings(ctx.h)
+        L.whisper_reset_timings(ctx.h)
+    finally:
+        L.whisper_log_set(C.cast(None, cb_t), None)
+    assert any("ms" in t for t in lines), lines
+    ctx.free()
+
+
 def test_batching_front_equals_one_call_at_a_time(wr, oracle, model_path):
     """handy_amd.manager.TranscriptionManager: concurrent transcribe() calls are served by shared GPU batches and
     every caller still gets exactly what a lone call returns (beam search, transcribe-rs defaults) -- which is the text the
