@@ -186,6 +186,12 @@ def load_library(path: Optional[str] = None):
     L.whisper_token_to_str.restype = C.POINTER(C.c_char); L.whisper_token_to_str.argtypes = [vp, ci]
     L.whisper_model_type_readable.restype = C.c_char_p; L.whisper_model_type_readable.argtypes = [vp]
     L.whisper_print_system_info.restype = C.c_char_p
+    L.whisper_print_timings.restype = None; L.whisper_print_timings.argtypes = [vp]
+    L.whisper_reset_timings.restype = None; L.whisper_reset_timings.argtypes = [vp]
+    L.whisper_full_default_params_by_ref.restype = C.POINTER(whisper_full_params); L.whisper_full_default_params_by_ref.argtypes = [ci]
+    L.whisper_free_params.restype = None; L.whisper_free_params.argtypes = [C.POINTER(whisper_full_params)]
+    L.whisper_full_get_segment_speaker_turn_next_from_state.restype = C.c_bool
+    L.whisper_full_get_segment_speaker_turn_next_from_state.argtypes = [vp, ci]
     L.wmi_version.restype = C.c_char_p
     L.whisper_full_n_segments_from_state.restype = ci; L.whisper_full_n_segments_from_state.argtypes = [vp]
     L.whisper_full_lang_id_from_state.restype = ci; L.whisper_full_lang_id_from_state.argtypes = [vp]

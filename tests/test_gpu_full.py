@@ -413,20 +413,15 @@ def test_low_level_entry_points(wr, model_path):
     # speaker turns: no tinydiarize token in this vocabulary's output
     s1.full(fp, pcm)
     assert s1.full_n_segments() >= 1
-    L.whisper_full_get_segment_speaker_turn_next_from_state.argtypes = [C.c_void_p, C.c_int]
-    L.whisper_full_get_segment_speaker_turn_next_from_state.restype = C.c_bool
     assert not any(L.whisper_full_get_segment_speaker_turn_next_from_state(s1.h, i) for i in range(s1.full_n_segments()))
     s1.free(); s2.free()
 
-    L.whisper_full_default_params_by_ref.restype = C.POINTER(wr.whisper_full_params)
-    L.whisper_full_default_params_by_ref.argtypes = [C.c_int]
     for strategy in (0, 1):
         pr = L.whisper_full_default_params_by_ref(strategy)
         by_val = L.whisper_full_default_params(strategy)
         assert pr and bytes(C.string_at(C.addressof(pr.contents), C.sizeof(wr.whisper_full_params))) == \
             bytes(C.string_at(C.addressof(by_val), C.sizeof(wr.whisper_full_params)))
-        L.whisper_free_params.argtypes = [C.c_void_p]; L.whisper_free_params.restype = None
-        L.whisper_free_params(C.cast(pr, C.c_void_p))
+        L.whisper_free_params(pr)
     info = L.whisper_print_system_info()
     assert info and (b"HIP" in info or b"gfx" in info or b"MI3" in info), info
 
@@ -436,8 +431,6 @@ def test_low_level_entry_points(wr, model_path):
     L.whisper_log_set.argtypes = [cb_t, C.c_void_p]; L.whisper_log_set.restype = None
     L.whisper_log_set(cb, None)
     try:
-        L.whisper_print_timings.argtypes = [C.c_void_p]; L.whisper_print_timings.restype = None
-        L.whisper_reset_timings.argtypes = [C.c_void_p]; L.whisper_reset_timings.restype = None
         L.whisper_print_timings(ctx.h)
         L.whisper_reset_timings(ctx.h)
     finally:
