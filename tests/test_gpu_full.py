@@ -439,6 +439,85 @@ def test_low_level_entry_points(wr, model_path):
     ctx.free()
 
 
+def test_context_level_entry_points(wr, model_path):
+    """whisper.h's calls that take the context and use its built-in state (whisper_init_from_file_with_params, whisper_full,
+    whisper_full_parallel, the accessors without `_from_state`, whisper_pcm_to_mel / whisper_encode / whisper_decode /
+    whisper_get_logits / whisper_lang_auto_detect, whisper_token_count, the model getters): the same results as the
+    state-taking calls the other tests use."""
+    path = model_path("micro", decisive=4.0)
+    L = wr.load_library()
+    vp, ci = C.c_void_p, C.c_int
+    L.whisper_init_from_file_with_params.restype = vp; L.whisper_init_from_file_with_params.argtypes = [C.c_char_p, wr.whisper_context_params]
+    L.whisper_context_default_params.restype = wr.whisper_context_params; L.whisper_context_default_params.argtypes = []
+    L.whisper_full.restype = ci; L.whisper_full.argtypes = [vp, wr.whisper_full_params, C.POINTER(C.c_float), ci]
+    L.whisper_full_parallel.restype = ci; L.whisper_full_parallel.argtypes = [vp, wr.whisper_full_params, C.POINTER(C.c_float), ci, ci]
+    for n, rt in (("whisper_full_n_segments", ci), ("whisper_full_lang_id", ci), ("whisper_n_len", ci), ("whisper_model_n_vocab", ci),
+                  ("whisper_model_n_audio_ctx", ci), ("whisper_model_n_text_ctx", ci), ("whisper_model_n_text_state", ci),
+                  ("whisper_model_n_text_head", ci), ("whisper_model_type", ci)):
+        getattr(L, n).restype = rt; getattr(L, n).argtypes = [vp]
+    for n, rt in (("whisper_full_get_segment_t0", C.c_int64), ("whisper_full_get_segment_t1", C.c_int64), ("whisper_full_get_segment_text", C.c_char_p),
+                  ("whisper_full_n_tokens", ci), ("whisper_full_get_segment_speaker_turn_next", C.c_bool)):
+        getattr(L, n).restype = rt; getattr(L, n).argtypes = [vp, ci]
+    L.whisper_full_get_token_id.restype = ci; L.whisper_full_get_token_id.argtypes = [vp, ci, ci]
+    L.whisper_full_get_token_p.restype = C.c_float; L.whisper_full_get_token_p.argtypes = [vp, ci, ci]
+    L.whisper_full_get_token_text.restype = C.c_char_p; L.whisper_full_get_token_text.argtypes = [vp, ci, ci]
+    L.whisper_full_get_token_data.restype = wr.whisper_token_data; L.whisper_full_get_token_data.argtypes = [vp, ci, ci]
+    L.whisper_pcm_to_mel.restype = ci; L.whisper_pcm_to_mel.argtypes = [vp, C.POINTER(C.c_float), ci, ci]
+    L.whisper_encode.restype = ci; L.whisper_encode.argtypes = [vp, ci, ci]
+    L.whisper_decode.restype = ci; L.whisper_decode.argtypes = [vp, C.POINTER(C.c_int32), ci, ci, ci]
+    L.whisper_get_logits.restype = C.POINTER(C.c_float); L.whisper_get_logits.argtypes = [vp]
+    L.whisper_lang_auto_detect.restype = ci; L.whisper_lang_auto_detect.argtypes = [vp, ci, ci, C.POINTER(C.c_float)]
+    L.whisper_token_count.restype = ci; L.whisper_token_count.argtypes = [vp, C.c_char_p]
+    L.whisper_lang_max_id.restype = ci; L.whisper_lang_max_id.argtypes = []
+    L.whisper_lang_str_full.restype = C.c_char_p; L.whisper_lang_str_full.argtypes = [ci]
+
+    pcm = np.ascontiguousarray(synth_pcm(31, 16000 * 14), np.float32)
+    fp = wr.FullParams(wr.SamplingStrategy.Greedy(1)); fp.set_temperature_inc(0.0); fp.set_language("auto")
+    # the reference result: context without a state + a state of its own
+    ctx = wr.WhisperContext(path); st = ctx.create_state()
+    st.full(fp, pcm)
+    want = [(st.full_get_segment_t0(i), st.full_get_segment_t1(i), [st.full_get_token_id(i, j) for j in range(st.full_n_tokens(i))])
+            for i in range(st.full_n_segments())]
+    want_lang = st.full_lang_id_from_state()
+    st.pcm_to_mel(pcm); st.encode(0)
+    sot = L.whisper_token_sot(ctx.h)
+    want_logits = st.decode([sot], 0)
+    want_vocab = ctx.n_vocab()
+    n_tok = len(ctx.tokenize(" kato 12"))
+    st.free(); ctx.free()
+
+    h = L.whisper_init_from_file_with_params(path.encode(), L.whisper_context_default_params())
+    assert h
+    try:
+        pp = pcm.ctypes.data_as(C.POINTER(C.c_float))
+        for call in ("full", "parallel"):
+            rc = L.whisper_full(h, fp.c, pp, pcm.size) if call == "full" else L.whisper_full_parallel(h, fp.c, pp, pcm.size, 1)
+            assert rc == 0
+            got = [(L.whisper_full_get_segment_t0(h, i), L.whisper_full_get_segment_t1(h, i),
+                    [L.whisper_full_get_token_id(h, i, j) for j in range(L.whisper_full_n_tokens(h, i))]) for i in range(L.whisper_full_n_segments(h))]
+            assert got == want and len(got) >= 1, (call, got, want)
+            assert L.whisper_full_lang_id(h) == want_lang
+            d = L.whisper_full_get_token_data(h, 0, 0)
+            assert d.id == want[0][2][0] and abs(d.p - L.whisper_full_get_token_p(h, 0, 0)) < 1e-7 and 0.0 < d.p <= 1.0
+            assert L.whisper_full_get_token_text(h, 0, 0) is not None and L.whisper_full_get_segment_text(h, 0) is not None
+            assert L.whisper_full_get_segment_speaker_turn_next(h, 0) is False
+        assert L.whisper_n_len(h) == 1 + (pcm.size + 200 - 400) // 160
+        assert L.whisper_pcm_to_mel(h, pp, pcm.size, 1) == 0 and L.whisper_encode(h, 0, 1) == 0
+        toks = (C.c_int32 * 1)(sot)
+        assert L.whisper_decode(h, toks, 1, 0, 1) == 0
+        logits = np.ctypeslib.as_array(L.whisper_get_logits(h), shape=(want_vocab,)).copy()
+        assert np.array_equal(logits, want_logits)
+        probs = (C.c_float * (L.whisper_lang_max_id() + 1))()
+        assert L.whisper_lang_auto_detect(h, 0, 1, probs) == want_lang
+        assert abs(sum(probs) - 1.0) < 1e-3
+        assert L.whisper_token_count(h, b" kato 12") == n_tok > 0
+        assert (L.whisper_model_n_vocab(h), L.whisper_model_n_audio_ctx(h), L.whisper_model_n_text_ctx(h)) == (want_vocab, 1500, 448)
+        assert L.whisper_model_n_text_state(h) > 0 and L.whisper_model_n_text_head(h) > 0 and L.whisper_model_type(h) >= 0
+        assert L.whisper_lang_str_full(0) == b"english"
+    finally:
+        L.whisper_free(h)
+
+
 def test_batching_front_equals_one_call_at_a_time(wr, oracle, model_path):
     """handy_amd.manager.TranscriptionManager: concurrent transcribe() calls are served by shared GPU batches and
     every caller still gets exactly what a lone call returns (beam search, transcribe-rs defaults) -- which is the text the
